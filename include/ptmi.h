@@ -1,0 +1,144 @@
+/*
+ * ptmi.h — C ABI of the MI355X wavefront path tracer (libptmi.so).
+ *
+ * Drop-in boundary for the reference's compute pass: the bind group of
+ * src/renderer/renderer.ts:368-381 (bindings 0..6 of src/shader/pt.wgsl:104-110)
+ * plus the per-frame camera write and dispatch of renderer.ts:403-431. Every
+ * blob is the exact WGSL-layout byte image the reference uploads
+ * (include/ptmi_layout.h). Plain pointers and sizes only — no HIP or torch
+ * types; a caller binds this with cgo / JNI / N-API / ctypes.
+ *
+ * There is no CPU backend behind this ABI. ptmi_create fails when no gfx950
+ * device is present.
+ *
+ * All functions return 0 on success and a negative PTMI_E_* code on failure;
+ * ptmi_last_error(ctx) (ctx may be NULL for creation errors) gives the text.
+ * A context is not thread-safe (like the reference's single-queue Renderer);
+ * work is ordered on one HIP stream per context.
+ */
+#ifndef PTMI_H
+#define PTMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "ptmi_layout.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTMI_ABI_VERSION 1
+
+enum {
+    PTMI_OK = 0,
+    PTMI_E_INVALID = -1,     /* bad argument / malformed blob */
+    PTMI_E_NODEVICE = -2,    /* no usable GPU */
+    PTMI_E_HIP = -3,         /* a HIP runtime call failed */
+    PTMI_E_STATE = -4,       /* call order (e.g. dispatch before upload/resize) */
+    PTMI_E_UNSUPPORTED = -5  /* scene exceeds an implementation limit */
+};
+
+enum { PTMI_ATLAS_RGBA16F = 1, PTMI_ATLAS_RGBA32F = 2 };   /* reference uploads rgba16float (renderer.ts:246-261) */
+enum { PTMI_TRAVERSAL_AUTO = 0, PTMI_TRAVERSAL_GLOBAL = 1, PTMI_TRAVERSAL_LDS = 2 };
+
+typedef struct ptmi_ctx ptmi_ctx;
+
+/* Runtime options. The reference fixes these at shader-compile time
+ * (pt.wgsl:5 MAX_BOUNCES = 8, :636 DO_MIS = true). */
+typedef struct ptmi_options {
+    uint32_t max_bounces;       /* 1..64; default 8 */
+    uint32_t do_mis;            /* 0/1; default 1 */
+    uint32_t tile_y0, tile_y1;  /* rows [y0,y1) this context renders; y1 = 0 -> height. Other rows are untouched */
+    uint32_t frames_per_batch;  /* frames traced together as one wavefront batch; 0 -> auto */
+    uint32_t traversal;         /* PTMI_TRAVERSAL_*; AUTO picks LDS when the scene fits */
+    uint32_t cull;              /* 1 (default): ordered traversal with conservative distance cull;
+                                   0: every box-overlapping leaf is tested, as pt.wgsl:248-291 does */
+    uint32_t timing;            /* 0: none; 1: HIP events around each dispatch (gpu_ms);
+                                   2: also around every extend/shade/shadow launch */
+    uint32_t reserved[8];
+} ptmi_options;
+
+typedef struct ptmi_stats {
+    uint64_t paths;             /* (pixel, frame) samples traced since the last reset */
+    uint64_t segments;          /* path segments = bounce-loop iterations reaching sceneIntersect (pt.wgsl:643-644) */
+    uint64_t shadow_rays;       /* shadow traversals (pt.wgsl:392/421/463) */
+    uint64_t dispatches;        /* ptmi_dispatch calls */
+    uint64_t frames;            /* frames traced */
+    uint64_t segments_by_bounce[64];
+    double   gpu_ms;            /* device time of all dispatches (HIP events on the context's stream) */
+    double   extend_ms;         /* ... of the closest-hit traversal kernel only, and its launch count */
+    uint64_t extend_launches;
+    double   shade_ms;
+    double   shadow_ms;
+    uint32_t bvh_depth;         /* of the uploaded tree */
+    uint32_t traversal_used;    /* PTMI_TRAVERSAL_GLOBAL or _LDS */
+    uint32_t frames_per_batch_used;
+    uint32_t reserved;
+} ptmi_stats;
+
+/* ---- lifetime ----------------------------------------------------------- */
+int ptmi_abi_version(void);
+/* device_ordinal >= 0 selects the HIP device. Replaces requestAdapter/requestDevice +
+ * createPipelines (renderer.ts:203-214, :513-533). */
+int ptmi_create(int device_ordinal, ptmi_ctx **out);
+int ptmi_destroy(ptmi_ctx *ctx);                              /* renderer.ts:482-494 destroy() */
+const char *ptmi_last_error(const ptmi_ctx *ctx);
+
+/* ---- resources (createBuffers, renderer.ts:242-355) --------------------- */
+/* The four storage buffers of bindings 1, 2, 4, 5. Host blobs are copied during the call. */
+int ptmi_upload_scene(ptmi_ctx *ctx,
+                      const ptmi_triangle *triangles, uint32_t n_triangles,
+                      const ptmi_material *materials, uint32_t n_materials,
+                      const ptmi_bvh_node *bvh_nodes, uint32_t n_nodes,
+                      const ptmi_light *lights, uint32_t n_lights);
+/* Binding 6. texels: width*height RGBA, row-major, texel (0,0) first. NULL/0 removes the atlas. */
+int ptmi_upload_atlas(ptmi_ctx *ctx, const void *texels, uint32_t width, uint32_t height, int format);
+/* Binding 0: (re)allocates the width*height*16-byte output buffer, zero-filled (renderer.ts:272-279, :496-510). */
+int ptmi_resize(ptmi_ctx *ctx, uint32_t width, uint32_t height);
+int ptmi_set_options(ptmi_ctx *ctx, const ptmi_options *opt);
+int ptmi_get_options(const ptmi_ctx *ctx, ptmi_options *opt);
+
+/* ---- the compute pass (updateCamera + dispatch, renderer.ts:403-431) ---- */
+/* Traces n_frames consecutive frames starting at camera->frame_index (one sample per
+ * pixel per frame, pt.wgsl:719) and folds them into the output buffer in frame
+ * order (pt.wgsl:753-761). Equals n_frames single-frame dispatches with the
+ * frame index incremented by the caller (renderer.ts:453). Asynchronous. */
+int ptmi_dispatch(ptmi_ctx *ctx, const ptmi_camera *camera, uint32_t n_frames);
+int ptmi_synchronize(ptmi_ctx *ctx);
+
+/* ---- output buffer (binding 0) ------------------------------------------ */
+/* width*height float4 (xyz = running mean, w = 0), index y*width+x. Synchronises. */
+int ptmi_read_output(ptmi_ctx *ctx, float *dst_rgba, size_t n_floats);
+int ptmi_write_output(ptmi_ctx *ctx, const float *src_rgba, size_t n_floats);
+/* Device-side access for zero-copy consumers (blit, RCCL gather): the buffer's
+ * device address, or a caller-owned device buffer of >= width*height*16 bytes to
+ * render into instead (like binding a GPUBuffer the caller created). */
+void *ptmi_output_device_ptr(ptmi_ctx *ctx);
+int ptmi_bind_output_device(ptmi_ctx *ctx, void *device_ptr, size_t bytes);
+/* Order this context's work on a caller-owned hipStream_t (NULL = the context's own). */
+int ptmi_set_stream(ptmi_ctx *ctx, void *hip_stream);
+
+/* ---- statistics ----------------------------------------------------------- */
+int ptmi_get_stats(ptmi_ctx *ctx, ptmi_stats *out);           /* synchronises */
+int ptmi_reset_stats(ptmi_ctx *ctx);
+
+/* ---- per-stage entry points (parity tests of single kernels) -------------- */
+/* raygen kernel (pt.wgsl:714-750) for explicit (x, y, frame) triples. o3/d3: n*3 floats. */
+int ptmi_debug_raygen(ptmi_ctx *ctx, const ptmi_camera *camera, uint32_t n, const uint32_t *xs,
+                      const uint32_t *ys, const uint32_t *frames, float *o3, float *d3, uint32_t *rng);
+/* extend kernel (pt.wgsl:248-296) on caller rays: t = -1 / tri = 0xFFFFFFFF on miss. */
+int ptmi_debug_intersect(ptmi_ctx *ctx, uint32_t n, const float *o3, const float *d3,
+                         float *t, uint32_t *tri, float *u, float *v);
+/* shadow kernel predicate (pt.wgsl:394/423/465); dist[i] < 0 = directional. */
+int ptmi_debug_occluded(ptmi_ctx *ctx, uint32_t n, const float *o3, const float *d3,
+                        const float *dist, uint8_t *occluded);
+/* arithmetic-contract probe: out[i] = op(a[i], b[i], c[i]) evaluated on the device.
+ * ops: 0 a/b, 1 sqrt(a), 2 fma(a,b,c), 3 min(a,b), 4 max(a,b), 5 sin(a), 6 cos(a),
+ *      7 pow5(a), 8 f32(u32 bits of a), 9 u32(a) as bits, 10 a - trunc(a), 11 tan(a) */
+int ptmi_debug_math(ptmi_ctx *ctx, int op, uint32_t n, const float *a, const float *b,
+                    const float *c, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTMI_H */

@@ -112,8 +112,21 @@ static inline float pow5(float x) {
     return (x2 * x2) * x;
 #endif
 }
-static inline float max1(float a, float b) { return fmaxf(a, b); }   /* IEEE maxNum */
-static inline float min1(float a, float b) { return fminf(a, b); }   /* IEEE minNum */
+/* WGSL min/max: the NaN and signed-zero cases are implementation-defined there;
+ * the contract takes the gfx950 v_max_f32 / v_min_f32 results: a NaN operand
+ * yields the other operand, max(+0,-0) = +0, min(+0,-0) = -0. */
+static inline float max1(float a, float b) {
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a == 0.0f && b == 0.0f) return signbit(a) ? b : a;
+    return a >= b ? a : b;
+}
+static inline float min1(float a, float b) {
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a == 0.0f && b == 0.0f) return signbit(a) ? a : b;
+    return a <= b ? a : b;
+}
 
 /* sin/cos for x in [0, ~2*pi]: quadrant reduction (two-term Cody-Waite) and
  * degree-7/8 polynomials on [-pi/4, pi/4]; always hardware-fused in the
@@ -790,6 +803,30 @@ int pto_trace_path(const pto_scene *s, const ptmi_camera *cam, uint32_t x, uint3
     v3 col = trace(s, &rng, r, opt ? opt->max_bounces : 8u, opt ? (int)opt->do_mis : 1, &c, log16, &nl);
     radiance3[0] = col.x; radiance3[1] = col.y; radiance3[2] = col.z;
     return nl;
+}
+
+/* arithmetic-contract probe, same op codes as ptmi_debug_math (include/ptmi.h) */
+void pto_math(int op, uint32_t n, const float *a, const float *b, const float *c, float *out) {
+    for (uint32_t i = 0; i < n; i++) {
+        float x = a[i], y = b ? b[i] : 0.0f, z = c ? c[i] : 0.0f, r = 0.0f, t;
+        uint32_t bits;
+        switch (op) {
+        case 0: r = x / y; break;
+        case 1: r = sqrtf(x); break;
+        case 2: r = __builtin_fmaf(x, y, z); break;
+        case 3: r = min1(x, y); break;
+        case 4: r = max1(x, y); break;
+        case 5: sincos1(x, &r, &t); break;
+        case 6: sincos1(x, &t, &r); break;
+        case 7: r = pow5(x); break;
+        case 8: memcpy(&bits, &x, 4); r = (float)bits; break;
+        case 9: bits = f2u(x); memcpy(&r, &bits, 4); break;
+        case 10: r = x - truncf(x); break;
+        case 11: r = tan1(x); break;
+        default: break;
+        }
+        out[i] = r;
+    }
 }
 
 /* ------------------------------------------------------------------------- */

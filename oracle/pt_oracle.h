@@ -100,6 +100,10 @@ int pto_render(const pto_scene *s, const ptmi_camera *cam, uint32_t n_frames,
 int pto_trace_path(const pto_scene *s, const ptmi_camera *cam, uint32_t x, uint32_t y,
                    uint32_t frame, const pto_options *opt, float *radiance3, float *log16);
 
+/* out[i] = op(a[i], b[i], c[i]) with the contract's scalar helpers; op codes as
+ * ptmi_debug_math in include/ptmi.h */
+void pto_math(int op, uint32_t n, const float *a, const float *b, const float *c, float *out);
+
 /* per-function probes used by the analytic KAT tests */
 void pto_eval_bsdf(const float albedo[3], float roughness, float metallic, float transmission,
                    float ior, const float n[3], const float v[3], const float l[3], int front,

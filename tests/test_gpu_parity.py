@@ -1,0 +1,216 @@
+"""GPU parity: the HIP kernels, called through the C ABI (libptmi.so), against the CPU
+oracle on identical inputs. The bar is bit-exact — the oracle's contract build and the
+kernels implement the same IEEE-754 operation order — for the integer RNG,
+for (t, triangle, u, v) of every ray and for every output float."""
+import numpy as np
+import pytest
+
+from ptmi import layout
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_same_floats(a, b, what):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    both_nan = np.isnan(a) & np.isnan(b)
+    bad = (bits(a) != bits(b)) & ~both_nan
+    if bad.any():
+        idx = np.argwhere(bad)[:5]
+        raise AssertionError(f"{what}: {bad.sum()} of {bad.size} floats differ; first at {idx.tolist()}: "
+                             f"gpu={a[tuple(idx[0])]!r} oracle={b[tuple(idx[0])]!r}")
+
+
+# ---------------------------------------------------------------------------------
+def test_math_contract(gpu_ctx, oracle):
+    import ctypes
+    rng = np.random.default_rng(7)
+    n = 200_000
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-38, -1e-38, 1e-45, 3.4e38, 2.5,
+                        0.5, 4294967040.0, 4294967296.0, 16777217.0], np.float32)
+    a = np.concatenate([special, rng.standard_normal(n).astype(np.float32) * 10,
+                        (rng.random(n) * 6.2832).astype(np.float32)])
+    b = np.concatenate([special[::-1], rng.standard_normal(n).astype(np.float32),
+                        rng.standard_normal(n).astype(np.float32) * 1e-3])
+    c = np.concatenate([special, rng.standard_normal(2 * n).astype(np.float32)])
+    for op, name in enumerate(["div", "sqrt", "fma", "min", "max", "sin", "cos", "pow5", "u2f", "f2u", "frac", "tan"]):
+        x = a
+        if name in ("sin", "cos", "tan"):
+            x = np.abs(a) % np.float32(6.3)
+            x[np.isnan(x)] = 0.5
+        if name == "sqrt":
+            x = np.abs(a)
+        ref = np.zeros_like(x)
+        p = lambda q: q.ctypes.data_as(ctypes.c_void_p)
+        oracle.L.pto_math(op, x.size, p(x), p(b), p(c), p(ref))
+        got = gpu_ctx.debug_math(op, x, b, c)
+        assert_same_floats(got, ref, f"math op {name}")
+
+
+@pytest.mark.parametrize("aperture", [0.0, 0.001, 0.05])
+def test_raygen_parity(gpu_ctx, oracle, aperture):
+    cam = layout.make_camera(1920, 1080, aperture=aperture, focus_distance=2.8)
+    rng = np.random.default_rng(3)
+    n = 100_000
+    xs = rng.integers(0, 1920, n).astype(np.uint32)
+    ys = rng.integers(0, 1080, n).astype(np.uint32)
+    fr = rng.integers(0, 512, n).astype(np.uint32)
+    xs[:4], ys[:4], fr[:4] = [0, 1, 3, 1919], [0, 0, 2, 1079], [0, 0, 5, 63]      # SURVEY App. B seeds
+    go, gd, grng = gpu_ctx.debug_raygen(cam, xs, ys, fr)
+    oo, od, orng = oracle.raygen(cam, xs, ys, fr)
+    assert np.array_equal(grng, orng)
+    assert_same_floats(go, oo, "ray origin")
+    assert_same_floats(gd, od, "ray direction")
+
+
+def _test_rays(scene, n, seed):
+    """Primary rays, interior random rays, axis-parallel and degenerate directions."""
+    rng = np.random.default_rng(seed)
+    o = np.empty((n, 3), np.float32)
+    d = rng.standard_normal((n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    lo = scene.nodes[0]["aabb_min"]
+    hi = scene.nodes[0]["aabb_max"]
+    o[:] = lo + (hi - lo) * rng.random((n, 3)).astype(np.float32)
+    k = n // 4
+    o[:k] = (0.0, 1.0, 2.8)                       # camera position: coherent primary-like rays
+    d[:k, 2] = -np.abs(d[:k, 2]) - 1.0
+    d[:k] /= np.linalg.norm(d[:k], axis=1, keepdims=True)
+    d[k:k + 64] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 64)]          # exact zeros in d
+    o[k + 64:k + 128] = scene.tris["v0"][rng.integers(0, len(scene.tris), 64)]  # origins on vertices
+    return o, d.astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["cornell", "feature_box", "cornell_spheres"])
+@pytest.mark.parametrize("cull", [1, 0])
+@pytest.mark.parametrize("trav", ["global", "lds"])
+def test_extend_parity(gpu_ctx, oracle, scene_factory, name, cull, trav):
+    from ptmi import native
+    sc = scene_factory(name)
+    gpu_ctx.upload_scene(sc)
+    mode = native.TRAVERSAL_GLOBAL if trav == "global" else native.TRAVERSAL_AUTO
+    gpu_ctx.set_options(cull=cull, traversal=mode)
+    o, d = _test_rays(sc, 300_000, 11)
+    gt, gtri, gu, gv = gpu_ctx.debug_intersect(o, d)
+    ot, otri, ou, ov, _ = oracle.intersect(sc, o, d)
+    assert (ot > 0).mean() > 0.5
+    assert np.array_equal(gtri, otri), f"{(gtri != otri).sum()} triangle ids differ"
+    assert_same_floats(gt, ot, "t")
+    assert_same_floats(gu, ou, "u")
+    assert_same_floats(gv, ov, "v")
+    gpu_ctx.set_options(cull=1, traversal=native.TRAVERSAL_AUTO)
+
+
+@pytest.mark.parametrize("name", ["cornell", "feature_box"])
+def test_occluded_parity(gpu_ctx, oracle, scene_factory, name):
+    sc = scene_factory(name)
+    gpu_ctx.upload_scene(sc)
+    o, d = _test_rays(sc, 200_000, 5)
+    rng = np.random.default_rng(9)
+    dist = (rng.random(len(o)) * 2.5).astype(np.float32)
+    dist[::5] = -1.0                                        # directional-light rays
+    # put some limits exactly at the closest hit distance (the t < dist - 2e-6 edge)
+    ot, _, _, _, _ = oracle.intersect(sc, o, d)
+    sel = (ot > 0) & (np.arange(len(o)) % 7 == 0)
+    dist[sel] = ot[sel]
+    sel2 = (ot > 0) & (np.arange(len(o)) % 7 == 1)
+    dist[sel2] = ot[sel2] + np.float32(3e-6)
+    for cull in (1, 0):
+        gpu_ctx.set_options(cull=cull)
+        g = gpu_ctx.debug_occluded(o, d, dist)
+        r = oracle.occluded(sc, o, d, dist)
+        assert 0.05 < r.mean() < 0.95
+        assert np.array_equal(g, r), f"{(g != r).sum()} shadow predicates differ (cull={cull})"
+    gpu_ctx.set_options(cull=1)
+
+
+RENDER_CASES = [
+    # scene, W, H, frames, bounces, mis, aperture
+    ("cornell", 96, 64, 6, 8, 1, 0.001),
+    ("cornell", 64, 64, 4, 4, 0, 0.001),          # BASELINE config 1 shape (MIS off, 4 bounces), reduced
+    ("cornell_glass", 80, 60, 5, 8, 1, 0.0),
+    ("feature_box", 72, 72, 6, 8, 1, 0.05),
+    ("cornell_spheres", 64, 48, 3, 8, 1, 0.001),
+]
+
+
+@pytest.mark.parametrize("case", RENDER_CASES, ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}x{c[3]}-b{c[4]}-mis{c[5]}")
+def test_render_parity(gpu_ctx, oracle, scene_factory, case):
+    name, W, H, frames, bounces, mis, ap = case
+    sc = scene_factory(name)
+    cam = layout.make_camera(W, H, aperture=ap, focus_distance=2.8)
+    ref, ost = oracle.render(sc, cam, frames, max_bounces=bounces, do_mis=mis)
+    gpu_ctx.upload_scene(sc)
+    gpu_ctx.resize(W, H)
+    gpu_ctx.set_options(max_bounces=bounces, do_mis=mis, tile_y0=0, tile_y1=0, frames_per_batch=0, cull=1)
+    gpu_ctx.reset_stats()
+    gpu_ctx.dispatch(cam, frames)
+    got = gpu_ctx.read_output()
+    st = gpu_ctx.stats()
+    assert st.segments == ost.segments, (st.segments, ost.segments)
+    assert st.shadow_rays == ost.shadow_rays, (st.shadow_rays, ost.shadow_rays)
+    assert st.paths == ost.paths
+    assert_same_floats(got, ref, f"radiance {name}")
+    assert np.isfinite(got).all() and got[..., :3].mean() > 0.01
+
+
+def test_dispatch_batching_equivalence(gpu_ctx, scene_factory):
+    """n_frames in one dispatch == n single-frame dispatches == any batch size (include/ptmi.h)."""
+    sc = scene_factory("cornell")
+    W, H, frames = 64, 48, 7
+    gpu_ctx.upload_scene(sc)
+    gpu_ctx.resize(W, H)
+    outs = []
+    for fpb in (1, 3, 0):
+        gpu_ctx.resize(W, H)
+        gpu_ctx.set_options(max_bounces=8, do_mis=1, frames_per_batch=fpb, tile_y0=0, tile_y1=0)
+        gpu_ctx.dispatch(layout.make_camera(W, H), frames)
+        outs.append(gpu_ctx.read_output())
+    gpu_ctx.resize(W, H)
+    gpu_ctx.set_options(frames_per_batch=0)
+    for f in range(frames):                                   # the reference's loop: renderer.ts:415-454
+        gpu_ctx.dispatch(layout.make_camera(W, H, frame_index=f), 1)
+    outs.append(gpu_ctx.read_output())
+    for o in outs[1:]:
+        assert np.array_equal(bits(o), bits(outs[0]))
+
+
+def test_tile_rows_and_traversal_modes(gpu_ctx, oracle, scene_factory):
+    """Row bands (the multi-GPU shard unit) and every traversal mode give the same bits."""
+    from ptmi import native
+    sc = scene_factory("cornell")
+    W, H, frames = 64, 60, 3
+    cam = layout.make_camera(W, H)
+    ref, _ = oracle.render(sc, cam, frames)
+    gpu_ctx.upload_scene(sc)
+    for mode, cull in ((native.TRAVERSAL_GLOBAL, 1), (native.TRAVERSAL_LDS, 1), (native.TRAVERSAL_GLOBAL, 0),
+                       (native.TRAVERSAL_LDS, 0)):
+        gpu_ctx.resize(W, H)
+        gpu_ctx.set_options(max_bounces=8, do_mis=1, traversal=mode, cull=cull, frames_per_batch=0, tile_y0=0, tile_y1=0)
+        for y0, y1 in ((0, 17), (17, 40), (40, 60)):
+            gpu_ctx.set_options(tile_y0=y0, tile_y1=y1)
+            gpu_ctx.dispatch(cam, frames)
+        assert_same_floats(gpu_ctx.read_output(), ref, f"bands mode={mode} cull={cull}")
+    gpu_ctx.set_options(traversal=native.TRAVERSAL_AUTO, cull=1, tile_y0=0, tile_y1=0)
+
+
+def test_errors_are_loud(gpu_ctx, scene_factory):
+    from ptmi import native
+    sc = scene_factory("cornell")
+    gpu_ctx.upload_scene(sc)
+    gpu_ctx.resize(32, 32)
+    with pytest.raises(native.PtmiError):
+        gpu_ctx.dispatch(layout.make_camera(64, 64), 1)            # camera / buffer size mismatch
+    with pytest.raises(native.PtmiError):
+        gpu_ctx.set_options(max_bounces=0)
+    bad = sc.nodes.copy()
+    bad["left"][0] = len(bad) + 5
+    import copy
+    sc2 = copy.copy(sc)
+    sc2.nodes = bad
+    with pytest.raises(native.PtmiError):
+        gpu_ctx.upload_scene(sc2)
+    gpu_ctx.upload_scene(sc)

@@ -1,0 +1,206 @@
+// pipeline.hip — the stream kernels around traversal and shading:
+//   raygen      camera rays + RNG seeding          (reference: src/shader/pt.wgsl:714-750)
+//   compact     ordered compaction of survivors    (no reference counterpart: the megakernel
+//               keeps dead lanes idle; here ballot words -> popcount prefix -> scatter)
+//   accumulate  clamp + running mean in frame order (pt.wgsl:751-761)
+#include "pt_device.h"
+#include "pt_math.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+// pt.wgsl:719-750
+PT_DEV void camera_ray(const ptmi_camera &cam, uint32_t x, uint32_t y, uint32_t frame, v3 &org, v3 &dir,
+                       uint32_t &rng) {
+    rng = rng_seed(x, y, frame);
+    float jx = rng_f(rng), jy = rng_f(rng);
+    float px = (float)x + jx, py = (float)y + jy;
+    float uvx = (px / (float)cam.width) * 2.0f - 1.0f;
+    float uvy = (py / (float)cam.height) * 2.0f - 1.0f;
+    float th = tan1(cam.fov * 0.5f);
+    v3 fw = mk3(cam.forward[0], cam.forward[1], cam.forward[2]);
+    v3 rt = mk3(cam.right[0], cam.right[1], cam.right[2]);
+    v3 up = mk3(cam.up[0], cam.up[1], cam.up[2]);
+    v3 pos = mk3(cam.position[0], cam.position[1], cam.position[2]);
+    v3 a = scale3(scale3(scale3(rt, uvx), th), cam.aspect);
+    v3 b = scale3(scale3(up, uvy), th);
+    dir = normalize3(add3(add3(fw, a), b));
+    org = pos;
+    if (cam.aperture > 0.0f) {
+        v3 focal = madd3(dir, cam.focus_distance, pos);
+        float r = __builtin_sqrtf(rng_f(rng)) * cam.aperture;
+        float theta = rng_f(rng) * 2.0f * PT_PI;
+        float st, ct; sincos1(theta, st, ct);
+        v3 off = madd3(up, r * st, scale3(rt, r * ct));
+        org = add3(pos, off);
+        dir = normalize3(sub3(focal, org));
+    }
+}
+
+PT_DEV void init_path(DevPaths P, uint32_t p, v3 o, v3 d, uint32_t rng) {
+    P.O[p] = make_float4(o.x, o.y, o.z, __uint_as_float(rng));
+    P.D[p] = make_float4(d.x, d.y, d.z, 0.0f);
+    P.T[p] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);      // pt.wgsl:639
+    P.L[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);      // pt.wgsl:640
+}
+
+// path id = frame_in_batch * band_pixels + (y - y0) * width + x
+__global__ __launch_bounds__(BLOCK) void k_raygen(ptmi_camera cam, DevBand band, uint32_t frame0, uint32_t n_frames,
+                                                  DevPaths P, uint32_t *__restrict__ queue,
+                                                  uint32_t *__restrict__ count_out) {
+    const uint32_t npix = (band.y1 - band.y0) * band.width;
+    const uint32_t total = npix * n_frames;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = total;
+    for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < total; p += gridDim.x * BLOCK) {
+        uint32_t k = p / npix, pix = p - k * npix;
+        uint32_t y = band.y0 + pix / band.width, x = pix % band.width;
+        v3 o, d; uint32_t rng;
+        camera_ray(cam, x, y, frame0 + k, o, d, rng);
+        init_path(P, p, o, d, rng);
+        queue[p] = p;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_raygen_list(ptmi_camera cam, uint32_t n, const uint32_t *xs,
+                                                       const uint32_t *ys, const uint32_t *frames, DevPaths P) {
+    uint32_t p = blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= n) return;
+    v3 o, d; uint32_t rng;
+    camera_ray(cam, xs[p], ys[p], frames[p], o, d, rng);
+    init_path(P, p, o, d, rng);
+}
+
+// ---- ordered compaction ------------------------------------------------------
+// Phase 1 (one 1024-thread workgroup): exclusive prefix of popcount(alive word) over the
+// ceil(count/64) ballot words written by `shade`; also totals the statistics.
+constexpr int SCAN_BLOCK = 1024;
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_masks(const uint32_t *__restrict__ count_ptr,
+                                                           const uint64_t *__restrict__ alive,
+                                                           const uint64_t *__restrict__ shadow,
+                                                           uint32_t *__restrict__ word_off,
+                                                           uint32_t *__restrict__ next_count,
+                                                           unsigned long long *__restrict__ stats, uint32_t bounce) {
+    __shared__ uint32_t part[SCAN_BLOCK];
+    __shared__ uint32_t spart[SCAN_BLOCK];
+    const uint32_t count = *count_ptr;
+    const uint32_t nwords = (count + 63u) >> 6;
+    const uint32_t per = (nwords + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    const uint32_t w0 = threadIdx.x * per;
+    const uint32_t w1 = w0 + per < nwords ? w0 + per : nwords;
+    uint32_t sum = 0, ssum = 0;
+    for (uint32_t w = w0; w < w1; w++) {
+        sum += (uint32_t)__popcll(alive[w]);
+        if (shadow) ssum += (uint32_t)__popcll(shadow[w]);
+    }
+    part[threadIdx.x] = sum; spart[threadIdx.x] = ssum;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over the 1024 partial sums
+    for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
+        uint32_t v = threadIdx.x >= (uint32_t)off ? part[threadIdx.x - off] : 0u;
+        uint32_t sv = threadIdx.x >= (uint32_t)off ? spart[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v; spart[threadIdx.x] += sv;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (uint32_t w = w0; w < w1; w++) {
+        word_off[w] = run;
+        run += (uint32_t)__popcll(alive[w]);
+    }
+    if (threadIdx.x == SCAN_BLOCK - 1) {
+        *next_count = part[threadIdx.x];
+        stats[0] += count;                       // segments
+        stats[1] += spart[threadIdx.x];          // shadow rays
+        stats[8 + bounce] += count;              // segments by bounce
+    }
+}
+
+// Phase 2: lane j of ballot word w keeps its path iff bit j is set; its slot in the next
+// queue is word_off[w] + popcount(bits below j). Queue order (ascending path id) is preserved.
+__global__ __launch_bounds__(BLOCK) void k_scatter(const uint32_t *__restrict__ count_ptr,
+                                                   const uint32_t *__restrict__ queue,
+                                                   const uint64_t *__restrict__ alive,
+                                                   const uint32_t *__restrict__ word_off,
+                                                   uint32_t *__restrict__ next_queue) {
+    const uint32_t count = *count_ptr;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
+        const uint64_t m = alive[i >> 6];
+        const uint32_t lane = i & 63u;
+        if ((m >> lane) & 1ull) {
+            uint32_t below = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            next_queue[word_off[i >> 6] + below] = queue ? queue[i] : i;
+        }
+    }
+}
+
+// pt.wgsl:751-761 for the batch's frames in ascending order
+__global__ __launch_bounds__(BLOCK) void k_accumulate(DevBand band, uint32_t frame0, uint32_t n_frames,
+                                                      const float4 *__restrict__ L, float4 *__restrict__ out) {
+    const uint32_t npix = (band.y1 - band.y0) * band.width;
+    for (uint32_t pix = blockIdx.x * BLOCK + threadIdx.x; pix < npix; pix += gridDim.x * BLOCK) {
+        const size_t oi = (size_t)band.y0 * band.width + pix;
+        float4 acc = out[oi];
+        for (uint32_t k = 0; k < n_frames; k++) {
+            float4 l = L[(size_t)k * npix + pix];
+            float cx = min1(l.x, 2.5f), cy = min1(l.y, 2.5f), cz = min1(l.z, 2.5f);
+            uint32_t frame = frame0 + k;
+            if (frame > 0u) {
+                float t = 1.0f / (float)(frame + 1u);
+                cx = mix1(acc.x, cx, t); cy = mix1(acc.y, cy, t); cz = mix1(acc.z, cz, t);
+            }
+            acc = make_float4(cx, cy, cz, 0.0f);
+        }
+        out[oi] = acc;
+    }
+}
+
+__global__ void k_math(int op, uint32_t n, const float *a, const float *b, const float *c, float *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = a[i], y = b ? b[i] : 0.0f, z = c ? c[i] : 0.0f, r = 0.0f, t;
+    switch (op) {
+    case 0: r = x / y; break;
+    case 1: r = __builtin_sqrtf(x); break;
+    case 2: r = fma1(x, y, z); break;
+    case 3: r = min1(x, y); break;
+    case 4: r = max1(x, y); break;
+    case 5: sincos1(x, r, t); break;
+    case 6: sincos1(x, t, r); break;
+    case 7: r = pow5(x); break;
+    case 8: r = (float)__float_as_uint(x); break;
+    case 9: r = __uint_as_float(f2u(x)); break;
+    case 10: r = x - __builtin_truncf(x); break;
+    case 11: r = tan1(x); break;
+    default: break;
+    }
+    out[i] = r;
+}
+
+}  // namespace
+
+void pt_launch_raygen(hipStream_t s, int blocks, const ptmi_camera &cam, DevBand band, uint32_t frame0,
+                      uint32_t n_frames, DevPaths p, uint32_t *queue, uint32_t *count_out) {
+    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(BLOCK), 0, s, cam, band, frame0, n_frames, p, queue, count_out);
+}
+void pt_launch_raygen_list(hipStream_t s, const ptmi_camera &cam, uint32_t n, const uint32_t *xs,
+                           const uint32_t *ys, const uint32_t *frames, DevPaths p) {
+    hipLaunchKernelGGL(k_raygen_list, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, cam, n, xs, ys, frames, p);
+}
+void pt_launch_compact(hipStream_t s, int blocks, const uint32_t *queue, const uint32_t *count,
+                       const uint64_t *alive_mask, const uint64_t *shadow_mask, uint32_t *word_offsets,
+                       uint32_t *next_queue, uint32_t *next_count, unsigned long long *stats, uint32_t bounce,
+                       int do_scatter) {
+    hipLaunchKernelGGL(k_scan_masks, dim3(1), dim3(SCAN_BLOCK), 0, s, count, alive_mask, shadow_mask, word_offsets,
+                       next_count, stats, bounce);
+    if (do_scatter)
+        hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(BLOCK), 0, s, count, queue, alive_mask, word_offsets,
+                           next_queue);
+}
+void pt_launch_accumulate(hipStream_t s, int blocks, DevBand band, uint32_t frame0, uint32_t n_frames,
+                          const float4 *L, float4 *out) {
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(BLOCK), 0, s, band, frame0, n_frames, L, out);
+}
+void pt_launch_math(hipStream_t s, int op, uint32_t n, const float *a, const float *b, const float *c, float *out) {
+    hipLaunchKernelGGL(k_math, dim3((n + 255) / 256), dim3(256), 0, s, op, n, a, b, c, out);
+}

@@ -1,0 +1,81 @@
+// pt_device.h — device-side data layout of the wavefront path tracer and the
+// kernel launch interface shared by the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ptmi_layout.h"
+
+// ---- traversal image of the scene (built at upload from the 48-B reference nodes) ----
+// Wide node, 64 B = 4 x float4: both children's boxes live in the parent, so one
+// fetch decides both subtrees.
+//   q0 = (Lmin.x, Lmin.y, Lmin.z, Lmax.x)
+//   q1 = (Lmax.y, Lmax.z, Rmin.x, Rmin.y)
+//   q2 = (Rmin.z, Rmax.x, Rmax.y, Rmax.z)
+//   q3 = bits(Lref, Rref, 0, 0)
+// Child reference: internal -> index of its wide node; leaf -> PT_REF_LEAF |
+// (count-1) << 26 | first triangle. Triangle image: 3 x float4 (v0, e1 = v1-v0,
+// e2 = v2-v0), the only triangle data the intersection test reads (pt.wgsl:128-156).
+#define PT_REF_LEAF      0x80000000u
+#define PT_REF_NONE      0xFFFFFFFFu
+#define PT_LEAF_MAX_TRIS 32u
+#define PT_LEAF_OFF_BITS 26u
+#define PT_LEAF_OFF_MASK ((1u << PT_LEAF_OFF_BITS) - 1u)
+
+struct DevScene {
+    const ptmi_triangle *tris;  uint32_t n_tris;
+    const ptmi_material *mats;  uint32_t n_mats;
+    const ptmi_light *lights;   uint32_t n_lights;
+    const void *atlas;          uint32_t atlas_w, atlas_h, atlas_fmt;   // 0 none, 1 rgba16f, 2 rgba32f
+    const float4 *wnodes;       uint32_t n_wnodes;
+    const float4 *tripos;
+    float root_min[3], root_max[3];
+    uint32_t root_ref;          // PT_REF_NONE: empty scene
+};
+
+// ---- path state: 64 B per path, four float4 streams indexed by path id ----
+//   O = (origin.xyz, bits(rng state))   D = (direction.xyz, 0)
+//   T = (throughput.xyz, 0)             L = (radiance.xyz, 0)
+struct DevPaths { float4 *O, *D, *T, *L; };
+// hit record, 16 B per queue slot: (t, u, v, bits(triangle index)); t = -1 on a miss
+// shadow record, 48 B per queue slot:
+//   SO = (origin.xyz, dist or -1 for directional)  SD = (wi.xyz, bits(path id))
+//   SC = (throughput * directLight .xyz, 0)   added to L[path] when unoccluded
+struct DevShadow { float4 *SO, *SD, *SC; };
+
+struct DevBand { uint32_t width, height, y0, y1; };      // rows [y0,y1) of a width x height frame
+
+struct ShadeParams {
+    uint32_t bounce, max_bounces, do_mis;
+};
+
+enum { PT_VARIANT_GLOBAL = 1, PT_VARIANT_LDS = 2 };
+
+struct TraverseConfig {
+    int variant;            // PT_VARIANT_*
+    int stack_entries;      // 16, 32 or 64
+    int cull;               // 0/1
+    size_t lds_scene_bytes; // LDS variant: bytes of wnodes + tripos
+};
+
+// ---- launchers (each enqueues on `s`; grids are persistent, sized by the caller) ----
+void pt_launch_raygen(hipStream_t s, int blocks, const ptmi_camera &cam, DevBand band, uint32_t frame0,
+                      uint32_t n_frames, DevPaths p, uint32_t *queue, uint32_t *count_out);
+void pt_launch_raygen_list(hipStream_t s, const ptmi_camera &cam, uint32_t n, const uint32_t *xs,
+                           const uint32_t *ys, const uint32_t *frames, DevPaths p);
+void pt_launch_extend(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, DevPaths p,
+                      const uint32_t *queue, const uint32_t *count, float4 *hits);
+void pt_launch_shadow(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, DevPaths p,
+                      DevShadow sh, const uint64_t *shadow_mask, const uint32_t *count, uint8_t *occluded_out);
+void pt_launch_shade(hipStream_t s, int blocks, const DevScene &sc, DevPaths p, const uint32_t *queue,
+                     const uint32_t *count, const float4 *hits, DevShadow sh, uint64_t *alive_mask,
+                     uint64_t *shadow_mask, ShadeParams sp);
+// ordered stream compaction of the survivors: masks -> next queue + its count, plus statistics
+void pt_launch_compact(hipStream_t s, int blocks, const uint32_t *queue, const uint32_t *count,
+                       const uint64_t *alive_mask, const uint64_t *shadow_mask, uint32_t *word_offsets,
+                       uint32_t *next_queue, uint32_t *next_count, unsigned long long *stats, uint32_t bounce,
+                       int do_scatter);
+void pt_launch_accumulate(hipStream_t s, int blocks, DevBand band, uint32_t frame0, uint32_t n_frames,
+                          const float4 *L, float4 *out);
+void pt_launch_math(hipStream_t s, int op, uint32_t n, const float *a, const float *b, const float *c, float *out);
+
+int pt_extend_set_lds_limit(size_t bytes);   // raises the dynamic-LDS cap of the LDS-variant kernels

@@ -1,0 +1,107 @@
+// pt_math.h — device-side arithmetic contract.
+//
+// Every helper names the exact IEEE-754 binary32 operation order the kernels use.
+// The translation unit is compiled with -ffp-contract=off -fno-fast-math, so the only
+// fused multiply-adds are the explicit __builtin_fmaf below; '/' and sqrtf are the
+// correctly rounded forms (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt);
+// min/max are v_min_f32 / v_max_f32 (NaN -> the other operand, max(+0,-0) = +0,
+// min(+0,-0) = -0). The WGSL operators these stand for are in src/shader/pt.wgsl
+// of the reference; the choices inside WGSL's accuracy envelope (reciprocal
+// multiply for vector/scalar division and the slab test, fused dot/cross/linear
+// combinations, pow5, polynomial sin/cos) are listed in DESIGN.md §3.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PT_PI  3.14159265359f     // pt.wgsl:3
+#define PT_EPS 1e-6f              // pt.wgsl:4
+#define PT_DEV __device__ __forceinline__
+
+struct v3 { float x, y, z; };
+struct v4 { float x, y, z, w; };
+
+PT_DEV v3 mk3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_DEV v3 xyz(float4 a) { return mk3(a.x, a.y, a.z); }
+PT_DEV float fma1(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+PT_DEV float min1(float a, float b) { return __builtin_fminf(a, b); }
+PT_DEV float max1(float a, float b) { return __builtin_fmaxf(a, b); }
+PT_DEV v3 add3(v3 a, v3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_DEV v3 sub3(v3 a, v3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_DEV v3 mul3(v3 a, v3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_DEV v3 scale3(v3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+PT_DEV v3 neg3(v3 a) { return mk3(-a.x, -a.y, -a.z); }
+// (ax*bx + ay*by) + az*bz, each step fused
+PT_DEV float dot3(v3 a, v3 b) { return fma1(a.z, b.z, fma1(a.y, b.y, a.x * b.x)); }
+PT_DEV v3 cross3(v3 a, v3 b) {
+    return mk3(fma1(a.y, b.z, -(a.z * b.y)), fma1(a.z, b.x, -(a.x * b.z)), fma1(a.x, b.y, -(a.y * b.x)));
+}
+PT_DEV v3 madd3(v3 a, float s, v3 b) { return mk3(fma1(a.x, s, b.x), fma1(a.y, s, b.y), fma1(a.z, s, b.z)); }
+PT_DEV v3 lincomb3(v3 a, float s1, v3 b, float s2, v3 c, float s3) {
+    return mk3(fma1(c.x, s3, fma1(b.x, s2, a.x * s1)), fma1(c.y, s3, fma1(b.y, s2, a.y * s1)),
+               fma1(c.z, s3, fma1(b.z, s2, a.z * s1)));
+}
+// WGSL vector / scalar: one IEEE reciprocal, three multiplies
+PT_DEV v3 vdiv3(v3 a, float s) { float inv = 1.0f / s; return mk3(a.x * inv, a.y * inv, a.z * inv); }
+PT_DEV float length3(v3 a) { return __builtin_sqrtf(dot3(a, a)); }
+PT_DEV v3 normalize3(v3 a) { return vdiv3(a, length3(a)); }
+PT_DEV float mix1(float a, float b, float t) { return fma1(b, t, a * (1.0f - t)); }
+PT_DEV v3 reflect3(v3 i, v3 n) {
+    float k = 2.0f * dot3(n, i);
+    return mk3(fma1(-k, n.x, i.x), fma1(-k, n.y, i.y), fma1(-k, n.z, i.z));
+}
+PT_DEV v3 refract3(v3 i, v3 n, float eta) {
+    float dn = dot3(n, i);
+    float k = 1.0f - (eta * eta) * (1.0f - dn * dn);
+    if (k < 0.0f) return mk3(0.0f, 0.0f, 0.0f);
+    float c = eta * dn + __builtin_sqrtf(k);
+    return mk3(fma1(-c, n.x, eta * i.x), fma1(-c, n.y, eta * i.y), fma1(-c, n.z, eta * i.z));
+}
+PT_DEV float pow5(float x) { float x2 = x * x; return (x2 * x2) * x; }
+
+// sin/cos on [0, ~2*pi]: quadrant reduction + fixed polynomials (same constants,
+// same fused steps as the oracle's contract build).
+PT_DEV void sincos1(float x, float &s, float &c) {
+    const float TWO_OVER_PI = 0.636619772f;
+    const float PIO2_HI = 1.57079637f;
+    const float PIO2_LO = -4.37113883e-08f;
+    float fk = __builtin_floorf(x * TWO_OVER_PI + 0.5f);
+    float r = fma1(-fk, PIO2_HI, x);
+    r = fma1(-fk, PIO2_LO, r);
+    float r2 = r * r;
+    float ps = fma1(-1.95152959e-4f, r2, 8.33216087e-3f);
+    ps = fma1(ps, r2, -1.66666546e-1f);
+    ps = fma1(ps, r2 * r, r);
+    float pc = fma1(2.44331571e-5f, r2, -1.38873163e-3f);
+    pc = fma1(pc, r2, 4.16666457e-2f);
+    pc = fma1(pc, r2 * r2, fma1(-0.5f, r2, 1.0f));
+    int q = (int)fk & 3;
+    float ss = (q & 1) ? pc : ps;
+    float cc = (q & 1) ? ps : pc;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
+}
+PT_DEV float tan1(float x) { float s, c; sincos1(x, s, c); return s / c; }
+
+// WGSL u32(f): truncating, saturating, NaN -> 0
+PT_DEV uint32_t f2u(float f) {
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)f;
+}
+
+// ---- RNG: src/shader/random.wgsl:3-16 ---------------------------------------
+PT_DEV uint32_t rng_seed(uint32_t x, uint32_t y, uint32_t frame) { return x + y * 1000u + frame * 100000u; }
+PT_DEV uint32_t rng_word(uint32_t &st) {
+    uint32_t s = st * 747796405u + 2891336453u;
+    st = s;
+    uint32_t r = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
+    return (r >> 22) ^ r;
+}
+// f32(word) / f32(4294967295.0): the divisor is 2^32 in f32, the quotient exact (can be 1.0)
+PT_DEV float rng_f(uint32_t &st) { return (float)rng_word(st) * 2.3283064365386963e-10f; }
+PT_DEV uint32_t rng_int(uint32_t &st, uint32_t lo, uint32_t hi) {
+    uint32_t span = hi - lo + 1u;
+    uint32_t k = f2u(rng_f(st) * (float)span);
+    if (k > hi - lo) k = hi - lo;       // rand()==1.0 would index one past the end
+    return lo + k;
+}

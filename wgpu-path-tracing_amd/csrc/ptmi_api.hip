@@ -1,0 +1,598 @@
+// ptmi_api.hip — the C ABI of include/ptmi.h: context, resource upload, the wavefront
+// dispatch loop and the per-stage debug entry points.
+//
+// Replaces the host side of the reference's compute pass (src/renderer/renderer.ts:
+// createBuffers :242-355, createBindGroups :368-381, updateCamera + dispatch :403-431).
+#include "ptmi.h"
+#include "pt_device.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_err;
+
+struct EventPair { hipEvent_t a, b; int kind; };   // kind: 0 dispatch, 1 extend, 2 shade, 3 shadow
+
+}  // namespace
+
+struct ptmi_ctx {
+    int device = 0, n_cu = 256;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    mutable std::string err;
+    ptmi_options opt{};
+
+    // scene (bindings 1, 2, 4, 5, 6)
+    void *d_tris = nullptr, *d_mats = nullptr, *d_lights = nullptr, *d_atlas = nullptr;
+    float4 *d_wnodes = nullptr, *d_tripos = nullptr;
+    DevScene sc{};
+    uint32_t bvh_depth = 0;
+    bool have_scene = false;
+    size_t lds_scene_bytes = 0;
+
+    // output (binding 0)
+    uint32_t W = 0, H = 0;
+    float4 *d_out_own = nullptr, *d_out = nullptr;
+
+    // wavefront batch buffers
+    size_t cap = 0;
+    DevPaths paths{};
+    float4 *hits = nullptr;
+    DevShadow sh{};
+    uint32_t *queue[2] = {nullptr, nullptr};
+    uint64_t *alive = nullptr, *shadowm = nullptr;
+    uint32_t *word_off = nullptr, *counts = nullptr;
+    unsigned long long *d_stats = nullptr;
+    uint8_t *d_occ = nullptr;
+
+    // statistics
+    ptmi_stats st{};
+    std::vector<EventPair> pending;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+constexpr int kStatsWords = 8 + 64;
+constexpr size_t kLdsMax = 160 * 1024;
+
+int fail(const ptmi_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) c->err = buf; else g_create_err = buf;
+    return code;
+}
+#define HIP_TRY(c, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    return fail((c), PTMI_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+template <class T> void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+void default_options(ptmi_options &o) {
+    std::memset(&o, 0, sizeof o);
+    o.max_bounces = 8; o.do_mis = 1; o.cull = 1; o.traversal = PTMI_TRAVERSAL_AUTO;
+}
+
+hipEvent_t get_event(ptmi_ctx *c) {
+    if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
+}
+
+// resolve finished event pairs into the statistics (stream must be synchronised)
+void drain_events(ptmi_ctx *c) {
+    for (auto &p : c->pending) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            switch (p.kind) {
+            case 0: c->st.gpu_ms += ms; break;
+            case 1: c->st.extend_ms += ms; c->st.extend_launches++; break;
+            case 2: c->st.shade_ms += ms; break;
+            case 3: c->st.shadow_ms += ms; break;
+            }
+        }
+        c->event_pool.push_back(p.a); c->event_pool.push_back(p.b);
+    }
+    c->pending.clear();
+}
+
+struct Timed {
+    ptmi_ctx *c; hipEvent_t a = nullptr, b = nullptr; int kind; bool on;
+    Timed(ptmi_ctx *c_, int kind_, bool on_) : c(c_), kind(kind_), on(on_) {
+        if (on) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); }
+    }
+    ~Timed() { if (on) { (void)hipEventRecord(b, c->stream); c->pending.push_back({a, b, kind}); } }
+};
+
+void free_batch(ptmi_ctx *c) {
+    dfree(c->paths.O); dfree(c->paths.D); dfree(c->paths.T); dfree(c->paths.L);
+    dfree(c->hits); dfree(c->sh.SO); dfree(c->sh.SD); dfree(c->sh.SC);
+    dfree(c->queue[0]); dfree(c->queue[1]); dfree(c->alive); dfree(c->shadowm); dfree(c->word_off); dfree(c->d_occ);
+    c->cap = 0;
+}
+
+int ensure_capacity(ptmi_ctx *c, size_t n) {
+    if (n <= c->cap) return PTMI_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_batch(c);
+    size_t cap = (n + 1023) & ~(size_t)1023;
+    size_t words = cap / 64 + 1;
+    HIP_TRY(c, hipMalloc(&c->paths.O, cap * 16)); HIP_TRY(c, hipMalloc(&c->paths.D, cap * 16));
+    HIP_TRY(c, hipMalloc(&c->paths.T, cap * 16)); HIP_TRY(c, hipMalloc(&c->paths.L, cap * 16));
+    HIP_TRY(c, hipMalloc(&c->hits, cap * 16));
+    HIP_TRY(c, hipMalloc(&c->sh.SO, cap * 16)); HIP_TRY(c, hipMalloc(&c->sh.SD, cap * 16));
+    HIP_TRY(c, hipMalloc(&c->sh.SC, cap * 16));
+    HIP_TRY(c, hipMalloc(&c->queue[0], cap * 4)); HIP_TRY(c, hipMalloc(&c->queue[1], cap * 4));
+    HIP_TRY(c, hipMalloc(&c->alive, words * 8)); HIP_TRY(c, hipMalloc(&c->shadowm, words * 8));
+    HIP_TRY(c, hipMalloc(&c->word_off, words * 4));
+    HIP_TRY(c, hipMalloc(&c->d_occ, cap));
+    c->cap = cap;
+    return PTMI_OK;
+}
+
+// ---- scene validation and the traversal image ---------------------------------
+struct Built {
+    std::vector<float4> wnodes, tripos;
+    float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
+    uint32_t root_ref = PT_REF_NONE, depth = 0;
+};
+
+uint32_t leaf_ref(const ptmi_bvh_node &n) {
+    return PT_REF_LEAF | ((n.triangle_count - 1u) << PT_LEAF_OFF_BITS) | n.triangle_offset;
+}
+
+int build_image(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_bvh_node *nodes, uint32_t nn, Built &b) {
+    if (nt == 0 || nn == 0) return PTMI_OK;                       // empty scene: every ray misses
+    if (nt > PT_LEAF_OFF_MASK) return fail(c, PTMI_E_UNSUPPORTED, "more than %u triangles", PT_LEAF_OFF_MASK);
+    // leaf <=> triangleCount > 0 (pt.wgsl:271)
+    auto check_leaf = [&](uint32_t i) -> int {
+        const ptmi_bvh_node &n = nodes[i];
+        if (n.triangle_count > PT_LEAF_MAX_TRIS)
+            return fail(c, PTMI_E_UNSUPPORTED, "BVH leaf %u holds %u triangles (limit %u)", i, n.triangle_count, PT_LEAF_MAX_TRIS);
+        if ((uint64_t)n.triangle_offset + n.triangle_count > nt)
+            return fail(c, PTMI_E_INVALID, "BVH leaf %u references triangles [%u,+%u) beyond %u", i, n.triangle_offset, n.triangle_count, nt);
+        return PTMI_OK;
+    };
+    std::vector<uint32_t> wide_of(nn, PT_REF_NONE);
+    std::vector<uint8_t> seen(nn, 0);
+    struct Item { uint32_t node, depth; };
+    std::vector<Item> stack;
+    // pass 1: preorder (left first) numbering of the internal nodes
+    stack.push_back({0u, 1u});
+    uint32_t n_wide = 0;
+    while (!stack.empty()) {
+        Item it = stack.back(); stack.pop_back();
+        if (it.node >= nn) return fail(c, PTMI_E_INVALID, "BVH child index %u out of range (%u nodes)", it.node, nn);
+        if (seen[it.node]) return fail(c, PTMI_E_INVALID, "BVH node %u is reachable twice", it.node);
+        seen[it.node] = 1;
+        b.depth = std::max(b.depth, it.depth);
+        if (it.depth > 65) return fail(c, PTMI_E_UNSUPPORTED, "BVH deeper than 65 levels (the reference's 64-entry stack, pt.wgsl:249)");
+        const ptmi_bvh_node &n = nodes[it.node];
+        if (n.triangle_count > 0) { int rc = check_leaf(it.node); if (rc) return rc; continue; }
+        wide_of[it.node] = n_wide++;
+        stack.push_back({n.right, it.depth + 1});
+        stack.push_back({n.left, it.depth + 1});
+    }
+    b.wnodes.assign((size_t)n_wide * 4, make_float4(0, 0, 0, 0));
+    auto ref_of = [&](uint32_t i) { return nodes[i].triangle_count > 0 ? leaf_ref(nodes[i]) : wide_of[i]; };
+    for (uint32_t i = 0; i < nn; i++) {
+        if (wide_of[i] == PT_REF_NONE) continue;
+        const ptmi_bvh_node &L = nodes[nodes[i].left], &R = nodes[nodes[i].right];
+        float4 *w = &b.wnodes[(size_t)wide_of[i] * 4];
+        w[0] = make_float4(L.aabb_min[0], L.aabb_min[1], L.aabb_min[2], L.aabb_max[0]);
+        w[1] = make_float4(L.aabb_max[1], L.aabb_max[2], R.aabb_min[0], R.aabb_min[1]);
+        w[2] = make_float4(R.aabb_min[2], R.aabb_max[0], R.aabb_max[1], R.aabb_max[2]);
+        uint32_t lr = ref_of(nodes[i].left), rr = ref_of(nodes[i].right);
+        float fl, fr; std::memcpy(&fl, &lr, 4); std::memcpy(&fr, &rr, 4);
+        w[3] = make_float4(fl, fr, 0.0f, 0.0f);
+    }
+    for (int k = 0; k < 3; k++) { b.root_min[k] = nodes[0].aabb_min[k]; b.root_max[k] = nodes[0].aabb_max[k]; }
+    b.root_ref = ref_of(0);
+    // triangle images: v0, e1 = v1 - v0, e2 = v2 - v0 (pt.wgsl:128-129; one IEEE subtraction each)
+    b.tripos.resize((size_t)nt * 3);
+    for (uint32_t i = 0; i < nt; i++) {
+        const ptmi_triangle &t = tris[i];
+        b.tripos[3 * (size_t)i + 0] = make_float4(t.v0[0], t.v0[1], t.v0[2], 0.0f);
+        b.tripos[3 * (size_t)i + 1] = make_float4(t.v1[0] - t.v0[0], t.v1[1] - t.v0[1], t.v1[2] - t.v0[2], 0.0f);
+        b.tripos[3 * (size_t)i + 2] = make_float4(t.v2[0] - t.v0[0], t.v2[1] - t.v0[1], t.v2[2] - t.v0[2], 0.0f);
+    }
+    return PTMI_OK;
+}
+
+int stack_entries_for(uint32_t depth) { return depth <= 17 ? 16 : depth <= 33 ? 32 : 64; }
+
+TraverseConfig traverse_config(const ptmi_ctx *c) {
+    TraverseConfig cfg{};
+    cfg.stack_entries = stack_entries_for(c->bvh_depth);
+    cfg.cull = c->opt.cull ? 1 : 0;
+    cfg.lds_scene_bytes = c->lds_scene_bytes;
+    bool fits = cfg.stack_entries <= 32 && c->lds_scene_bytes + (size_t)cfg.stack_entries * 1024 * 4 <= kLdsMax &&
+                c->sc.root_ref != PT_REF_NONE;
+    if (c->opt.traversal == PTMI_TRAVERSAL_GLOBAL) cfg.variant = PT_VARIANT_GLOBAL;
+    else cfg.variant = fits ? PT_VARIANT_LDS : PT_VARIANT_GLOBAL;
+    return cfg;
+}
+
+int check_ready(ptmi_ctx *c, bool need_output) {
+    if (!c) return PTMI_E_INVALID;
+    if (!c->have_scene) return fail(c, PTMI_E_STATE, "no scene uploaded (ptmi_upload_scene)");
+    if (need_output && (!c->d_out || c->W == 0 || c->H == 0)) return fail(c, PTMI_E_STATE, "no output buffer (ptmi_resize)");
+    return PTMI_OK;
+}
+
+int upload_rays(ptmi_ctx *c, uint32_t n, const float *o3, const float *d3, const float *w, float4 *dO, float4 *dD) {
+    std::vector<float4> o(n), d(n);
+    for (uint32_t i = 0; i < n; i++) {
+        o[i] = make_float4(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2], w ? w[i] : 0.0f);
+        d[i] = make_float4(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2], 0.0f);
+    }
+    HIP_TRY(c, hipMemcpyAsync(dO, o.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dD, d.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PTMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptmi_abi_version(void) { return PTMI_ABI_VERSION; }
+
+const char *ptmi_last_error(const ptmi_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int ptmi_create(int device_ordinal, ptmi_ctx **out) {
+    if (!out) return fail(nullptr, PTMI_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, PTMI_E_NODEVICE, "no HIP device available (%s); this library has no CPU backend",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device_ordinal < 0 || device_ordinal >= n)
+        return fail(nullptr, PTMI_E_INVALID, "device ordinal %d out of range (%d devices)", device_ordinal, n);
+    HIP_TRY(nullptr, hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device_ordinal));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, PTMI_E_NODEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only",
+                    device_ordinal, prop.gcnArchName);
+    ptmi_ctx *c = new ptmi_ctx();
+    c->device = device_ordinal;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    default_options(c->opt);
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c; return fail(nullptr, PTMI_E_HIP, "hipStreamCreate failed");
+    }
+    c->stream = c->own_stream;
+    if (hipMalloc(&c->counts, 80 * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(&c->d_stats, kStatsWords * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c->d_stats, 0, kStatsWords * sizeof(unsigned long long)) != hipSuccess) {
+        ptmi_destroy(c); return fail(nullptr, PTMI_E_HIP, "device allocation failed");
+    }
+    if (pt_extend_set_lds_limit(kLdsMax) != 0) {
+        ptmi_destroy(c); return fail(nullptr, PTMI_E_HIP, "cannot raise the dynamic LDS limit to %zu bytes", kLdsMax);
+    }
+    *out = c;
+    return PTMI_OK;
+}
+
+int ptmi_destroy(ptmi_ctx *c) {
+    if (!c) return PTMI_E_INVALID;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    drain_events(c);
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    free_batch(c);
+    dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_atlas); dfree(c->d_wnodes); dfree(c->d_tripos);
+    dfree(c->d_out_own); dfree(c->counts); dfree(c->d_stats);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return PTMI_OK;
+}
+
+int ptmi_upload_scene(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_material *mats, uint32_t nm,
+                      const ptmi_bvh_node *nodes, uint32_t nn, const ptmi_light *lights, uint32_t nl) {
+    if (!c) return PTMI_E_INVALID;
+    if ((nt && !tris) || (nm && !mats) || (nn && !nodes) || (nl && !lights))
+        return fail(c, PTMI_E_INVALID, "NULL blob with a non-zero count");
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (uint32_t i = 0; i < nl; i++) {
+        if (lights[i].light_type > PTMI_LIGHT_POINT)
+            return fail(c, PTMI_E_INVALID, "light %u has unknown type %u", i, lights[i].light_type);
+        if (lights[i].light_type == PTMI_LIGHT_EMISSIVE && lights[i].triangle_index >= nt)
+            return fail(c, PTMI_E_INVALID, "emissive light %u references triangle %u of %u", i, lights[i].triangle_index, nt);
+    }
+    Built b;
+    int rc = build_image(c, tris, nt, nodes, nn, b);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_wnodes); dfree(c->d_tripos);
+    auto up = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
+        if (bytes == 0) { bytes = 16; hipError_t e = hipMalloc(dst, bytes); if (e != hipSuccess) return e; return hipMemset(*dst, 0, bytes); }
+        hipError_t e = hipMalloc(dst, bytes); if (e != hipSuccess) return e;
+        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    HIP_TRY(c, up(&c->d_tris, tris, (size_t)nt * sizeof(ptmi_triangle)));
+    HIP_TRY(c, up(&c->d_mats, mats, (size_t)nm * sizeof(ptmi_material)));
+    HIP_TRY(c, up(&c->d_lights, lights, (size_t)nl * sizeof(ptmi_light)));
+    HIP_TRY(c, up(reinterpret_cast<void **>(&c->d_wnodes), b.wnodes.data(), b.wnodes.size() * 16));
+    HIP_TRY(c, up(reinterpret_cast<void **>(&c->d_tripos), b.tripos.data(), b.tripos.size() * 16));
+    DevScene &s = c->sc;
+    s.tris = static_cast<const ptmi_triangle *>(c->d_tris); s.n_tris = nt;
+    s.mats = static_cast<const ptmi_material *>(c->d_mats); s.n_mats = nm;
+    s.lights = static_cast<const ptmi_light *>(c->d_lights); s.n_lights = nl;
+    s.wnodes = c->d_wnodes; s.n_wnodes = (uint32_t)(b.wnodes.size() / 4);
+    s.tripos = c->d_tripos;
+    for (int k = 0; k < 3; k++) { s.root_min[k] = b.root_min[k]; s.root_max[k] = b.root_max[k]; }
+    s.root_ref = b.root_ref;
+    c->bvh_depth = b.depth;
+    c->lds_scene_bytes = b.wnodes.size() * 16 + b.tripos.size() * 16;
+    c->have_scene = true;
+    return PTMI_OK;
+}
+
+int ptmi_upload_atlas(ptmi_ctx *c, const void *texels, uint32_t w, uint32_t h, int fmt) {
+    if (!c) return PTMI_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    dfree(c->d_atlas);
+    c->sc.atlas = nullptr; c->sc.atlas_w = c->sc.atlas_h = c->sc.atlas_fmt = 0;
+    if (!texels || w == 0 || h == 0) return PTMI_OK;
+    if (fmt != PTMI_ATLAS_RGBA16F && fmt != PTMI_ATLAS_RGBA32F) return fail(c, PTMI_E_INVALID, "unknown atlas format %d", fmt);
+    size_t bytes = (size_t)w * h * (fmt == PTMI_ATLAS_RGBA16F ? 8 : 16);
+    HIP_TRY(c, hipMalloc(&c->d_atlas, bytes));
+    HIP_TRY(c, hipMemcpy(c->d_atlas, texels, bytes, hipMemcpyHostToDevice));
+    c->sc.atlas = c->d_atlas; c->sc.atlas_w = w; c->sc.atlas_h = h; c->sc.atlas_fmt = (uint32_t)fmt;
+    return PTMI_OK;
+}
+
+int ptmi_resize(ptmi_ctx *c, uint32_t w, uint32_t h) {
+    if (!c) return PTMI_E_INVALID;
+    if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 28)) return fail(c, PTMI_E_INVALID, "bad size %ux%u", w, h);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    dfree(c->d_out_own);
+    size_t bytes = (size_t)w * h * PTMI_OUTPUT_STRIDE;
+    HIP_TRY(c, hipMalloc(&c->d_out_own, bytes));
+    HIP_TRY(c, hipMemset(c->d_out_own, 0, bytes));
+    c->d_out = c->d_out_own; c->W = w; c->H = h;
+    return PTMI_OK;
+}
+
+int ptmi_set_options(ptmi_ctx *c, const ptmi_options *o) {
+    if (!c || !o) return PTMI_E_INVALID;
+    if (o->max_bounces < 1 || o->max_bounces > 64) return fail(c, PTMI_E_INVALID, "max_bounces %u not in 1..64", o->max_bounces);
+    if (o->traversal > PTMI_TRAVERSAL_LDS) return fail(c, PTMI_E_INVALID, "unknown traversal mode %u", o->traversal);
+    if (o->tile_y1 != 0 && o->tile_y0 >= o->tile_y1) return fail(c, PTMI_E_INVALID, "empty tile rows [%u,%u)", o->tile_y0, o->tile_y1);
+    c->opt = *o;
+    return PTMI_OK;
+}
+int ptmi_get_options(const ptmi_ctx *c, ptmi_options *o) {
+    if (!c || !o) return PTMI_E_INVALID;
+    *o = c->opt; return PTMI_OK;
+}
+
+int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (!cam) return fail(c, PTMI_E_INVALID, "camera is NULL");
+    if (cam->width != c->W || cam->height != c->H)
+        return fail(c, PTMI_E_INVALID, "camera says %ux%u but the output buffer is %ux%u", cam->width, cam->height, c->W, c->H);
+    if (n_frames == 0) return PTMI_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBand band{c->W, c->H, c->opt.tile_y0, c->opt.tile_y1 ? std::min(c->opt.tile_y1, c->H) : c->H};
+    if (band.y0 >= band.y1) return fail(c, PTMI_E_INVALID, "tile rows [%u,%u) outside the %u-row frame", band.y0, band.y1, c->H);
+    const uint64_t npix = (uint64_t)(band.y1 - band.y0) * band.width;
+    uint32_t F = c->opt.frames_per_batch;
+    if (F == 0) { F = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, (8ull << 20) / npix)); }
+    F = std::min(F, n_frames);
+    if (npix * F > 0xFFFFFF00ull) return fail(c, PTMI_E_UNSUPPORTED, "batch of %llu paths exceeds 2^32", (unsigned long long)(npix * F));
+    rc = ensure_capacity(c, (size_t)(npix * F));
+    if (rc) return rc;
+    TraverseConfig cfg = traverse_config(c);
+    if (c->opt.traversal == PTMI_TRAVERSAL_LDS && cfg.variant != PT_VARIANT_LDS)
+        return fail(c, PTMI_E_UNSUPPORTED, "scene needs %zu B of LDS plus the stack; it does not fit in %zu B", c->lds_scene_bytes, kLdsMax);
+    c->st.traversal_used = cfg.variant == PT_VARIANT_LDS ? PTMI_TRAVERSAL_LDS : PTMI_TRAVERSAL_GLOBAL;
+    c->st.frames_per_batch_used = F;
+    const int blocks = c->n_cu * 8;
+    const uint32_t maxb = c->opt.max_bounces;
+    const bool t1 = c->opt.timing >= 1, t2 = c->opt.timing >= 2;
+    {
+        Timed td(c, 0, t1);
+        for (uint32_t f0 = 0; f0 < n_frames; f0 += F) {
+            const uint32_t fb = std::min(F, n_frames - f0);
+            const uint32_t frame0 = cam->frame_index + f0;
+            pt_launch_raygen(c->stream, blocks, *cam, band, frame0, fb, c->paths, c->queue[0], &c->counts[0]);
+            int cur = 0;
+            for (uint32_t b = 0; b < maxb; b++) {
+                { Timed t(c, 1, t2); pt_launch_extend(c->stream, blocks, cfg, c->sc, c->paths, c->queue[cur], &c->counts[b], c->hits); }
+                { Timed t(c, 2, t2); pt_launch_shade(c->stream, blocks, c->sc, c->paths, c->queue[cur], &c->counts[b], c->hits, c->sh,
+                                                     c->alive, c->shadowm, ShadeParams{b, maxb, c->opt.do_mis}); }
+                if (c->opt.do_mis && c->sc.n_lights > 0) {
+                    Timed t(c, 3, t2);
+                    pt_launch_shadow(c->stream, blocks, cfg, c->sc, c->paths, c->sh, c->shadowm, &c->counts[b], nullptr);
+                }
+                const bool last = b + 1 == maxb;
+                pt_launch_compact(c->stream, blocks, c->queue[cur], &c->counts[b], c->alive,
+                                  (c->opt.do_mis && c->sc.n_lights > 0) ? c->shadowm : nullptr, c->word_off,
+                                  c->queue[cur ^ 1], &c->counts[b + 1], c->d_stats, b, last ? 0 : 1);
+                cur ^= 1;
+            }
+            pt_launch_accumulate(c->stream, blocks, band, frame0, fb, c->paths.L, c->d_out);
+        }
+    }
+    HIP_TRY(c, hipGetLastError());
+    c->st.paths += npix * n_frames;
+    c->st.frames += n_frames;
+    c->st.dispatches += 1;
+    return PTMI_OK;
+}
+
+int ptmi_synchronize(ptmi_ctx *c) {
+    if (!c) return PTMI_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    drain_events(c);
+    return PTMI_OK;
+}
+
+int ptmi_read_output(ptmi_ctx *c, float *dst, size_t n_floats) {
+    if (!c || !dst) return PTMI_E_INVALID;
+    if (!c->d_out) return fail(c, PTMI_E_STATE, "no output buffer (ptmi_resize)");
+    if (n_floats != (size_t)c->W * c->H * 4) return fail(c, PTMI_E_INVALID, "expected %zu floats, got %zu", (size_t)c->W * c->H * 4, n_floats);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    drain_events(c);
+    HIP_TRY(c, hipMemcpy(dst, c->d_out, n_floats * 4, hipMemcpyDeviceToHost));
+    return PTMI_OK;
+}
+
+int ptmi_write_output(ptmi_ctx *c, const float *src, size_t n_floats) {
+    if (!c || !src) return PTMI_E_INVALID;
+    if (!c->d_out) return fail(c, PTMI_E_STATE, "no output buffer (ptmi_resize)");
+    if (n_floats != (size_t)c->W * c->H * 4) return fail(c, PTMI_E_INVALID, "expected %zu floats, got %zu", (size_t)c->W * c->H * 4, n_floats);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(c->d_out, src, n_floats * 4, hipMemcpyHostToDevice));
+    return PTMI_OK;
+}
+
+void *ptmi_output_device_ptr(ptmi_ctx *c) { return c ? c->d_out : nullptr; }
+
+int ptmi_bind_output_device(ptmi_ctx *c, void *p, size_t bytes) {
+    if (!c) return PTMI_E_INVALID;
+    if (c->W == 0) return fail(c, PTMI_E_STATE, "call ptmi_resize first");
+    if (!p) { c->d_out = c->d_out_own; return PTMI_OK; }
+    if (bytes < (size_t)c->W * c->H * PTMI_OUTPUT_STRIDE) return fail(c, PTMI_E_INVALID, "buffer of %zu bytes is too small", bytes);
+    if (reinterpret_cast<uintptr_t>(p) & 15u) return fail(c, PTMI_E_INVALID, "buffer must be 16-byte aligned");
+    c->d_out = static_cast<float4 *>(p);
+    return PTMI_OK;
+}
+
+int ptmi_set_stream(ptmi_ctx *c, void *s) {
+    if (!c) return PTMI_E_INVALID;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    drain_events(c);
+    c->stream = s ? static_cast<hipStream_t>(s) : c->own_stream;
+    return PTMI_OK;
+}
+
+int ptmi_get_stats(ptmi_ctx *c, ptmi_stats *out) {
+    if (!c || !out) return PTMI_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    drain_events(c);
+    unsigned long long h[kStatsWords];
+    HIP_TRY(c, hipMemcpy(h, c->d_stats, sizeof h, hipMemcpyDeviceToHost));
+    c->st.segments = h[0]; c->st.shadow_rays = h[1];
+    for (int i = 0; i < 64; i++) c->st.segments_by_bounce[i] = h[8 + i];
+    c->st.bvh_depth = c->bvh_depth;
+    *out = c->st;
+    return PTMI_OK;
+}
+
+int ptmi_reset_stats(ptmi_ctx *c) {
+    if (!c) return PTMI_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    drain_events(c);
+    HIP_TRY(c, hipMemset(c->d_stats, 0, kStatsWords * sizeof(unsigned long long)));
+    uint32_t depth = c->bvh_depth;
+    std::memset(&c->st, 0, sizeof c->st);
+    c->st.bvh_depth = depth;
+    return PTMI_OK;
+}
+
+// ---- per-stage entry points ------------------------------------------------------
+int ptmi_debug_raygen(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n, const uint32_t *xs, const uint32_t *ys,
+                      const uint32_t *frames, float *o3, float *d3, uint32_t *rng) {
+    if (!c || !cam || !xs || !ys || !frames || !o3 || !d3) return PTMI_E_INVALID;
+    if (n == 0) return PTMI_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_capacity(c, n);
+    if (rc) return rc;
+    uint32_t *dx = c->queue[0], *dy = c->queue[1], *df = reinterpret_cast<uint32_t *>(c->hits);
+    HIP_TRY(c, hipMemcpyAsync(dx, xs, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dy, ys, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(df, frames, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    pt_launch_raygen_list(c->stream, *cam, n, dx, dy, df, c->paths);
+    std::vector<float4> o(n), d(n);
+    HIP_TRY(c, hipMemcpyAsync(o.data(), c->paths.O, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d.data(), c->paths.D, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < n; i++) {
+        o3[3 * i] = o[i].x; o3[3 * i + 1] = o[i].y; o3[3 * i + 2] = o[i].z;
+        d3[3 * i] = d[i].x; d3[3 * i + 1] = d[i].y; d3[3 * i + 2] = d[i].z;
+        if (rng) std::memcpy(&rng[i], &o[i].w, 4);
+    }
+    return PTMI_OK;
+}
+
+int ptmi_debug_intersect(ptmi_ctx *c, uint32_t n, const float *o3, const float *d3, float *t, uint32_t *tri,
+                         float *u, float *v) {
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (!o3 || !d3 || !t || !tri || !u || !v) return fail(c, PTMI_E_INVALID, "NULL argument");
+    if (n == 0) return PTMI_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    rc = ensure_capacity(c, n);
+    if (rc) return rc;
+    rc = upload_rays(c, n, o3, d3, nullptr, c->paths.O, c->paths.D);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(&c->counts[0], &n, 4, hipMemcpyHostToDevice, c->stream));
+    TraverseConfig cfg = traverse_config(c);
+    if (c->opt.traversal == PTMI_TRAVERSAL_LDS && cfg.variant != PT_VARIANT_LDS)
+        return fail(c, PTMI_E_UNSUPPORTED, "scene does not fit in LDS");
+    pt_launch_extend(c->stream, c->n_cu * 8, cfg, c->sc, c->paths, nullptr, &c->counts[0], c->hits);
+    std::vector<float4> h(n);
+    HIP_TRY(c, hipMemcpyAsync(h.data(), c->hits, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    for (uint32_t i = 0; i < n; i++) {
+        t[i] = h[i].x; u[i] = h[i].y; v[i] = h[i].z; std::memcpy(&tri[i], &h[i].w, 4);
+    }
+    return PTMI_OK;
+}
+
+int ptmi_debug_occluded(ptmi_ctx *c, uint32_t n, const float *o3, const float *d3, const float *dist, uint8_t *occ) {
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (!o3 || !d3 || !dist || !occ) return fail(c, PTMI_E_INVALID, "NULL argument");
+    if (n == 0) return PTMI_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    rc = ensure_capacity(c, n);
+    if (rc) return rc;
+    rc = upload_rays(c, n, o3, d3, dist, c->sh.SO, c->sh.SD);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(&c->counts[0], &n, 4, hipMemcpyHostToDevice, c->stream));
+    TraverseConfig cfg = traverse_config(c);
+    pt_launch_shadow(c->stream, c->n_cu * 8, cfg, c->sc, c->paths, c->sh, nullptr, &c->counts[0], c->d_occ);
+    HIP_TRY(c, hipMemcpyAsync(occ, c->d_occ, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    return PTMI_OK;
+}
+
+int ptmi_debug_math(ptmi_ctx *c, int op, uint32_t n, const float *a, const float *b, const float *cc, float *out) {
+    if (!c || !a || !out) return PTMI_E_INVALID;
+    if (n == 0) return PTMI_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    float *da = nullptr, *db = nullptr, *dc = nullptr, *dout = nullptr;
+    size_t bytes = (size_t)n * 4;
+    HIP_TRY(c, hipMalloc(&da, bytes)); HIP_TRY(c, hipMalloc(&dout, bytes));
+    HIP_TRY(c, hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
+    if (b) { HIP_TRY(c, hipMalloc(&db, bytes)); HIP_TRY(c, hipMemcpy(db, b, bytes, hipMemcpyHostToDevice)); }
+    if (cc) { HIP_TRY(c, hipMalloc(&dc, bytes)); HIP_TRY(c, hipMemcpy(dc, cc, bytes, hipMemcpyHostToDevice)); }
+    pt_launch_math(c->stream, op, n, da, db, dc, dout);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
+    dfree(da); dfree(db); dfree(dc); dfree(dout);
+    return PTMI_OK;
+}
+
+}  // extern "C"

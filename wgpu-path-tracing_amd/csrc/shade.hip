@@ -1,0 +1,350 @@
+// shade.hip — the shade / next-event kernel of the wavefront path tracer.
+//
+// One lane per queued path segment. From the hit record (t, u, v, triangle) written by
+// `extend` it rebuilds the shading state of the closest hit, applies emission, emits the
+// next-event (shadow) record, samples and evaluates the BSDF, advances the ray and
+// throughput, and plays Russian roulette — one iteration of the bounce loop of the
+// reference (src/shader/pt.wgsl:638-709) minus its two traversals. All RNG draws of the
+// bounce happen here, in the reference's order; the u32 RNG state
+// travels in O.w. Survivors and emitted shadow records are flagged with one wave ballot
+// each (64 paths -> one u64 word) for the ordered compaction kernel.
+#include "pt_device.h"
+#include "pt_math.h"
+
+namespace {
+
+struct HitInfo {                       // pt.wgsl:86-101 (fields the bounce loop reads)
+    v3 position; float t;
+    v3 normal;
+    v3 albedo;
+    float roughness, metallic, transmission, ior;
+    v3 emission; float emissive_strength;
+    bool is_front;
+};
+
+PT_DEV v3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
+
+PT_DEV v4 atlas_load(const DevScene &sc, uint32_t x, uint32_t y) {
+    v4 r; r.x = r.y = r.z = r.w = 0.0f;
+    if (sc.atlas_fmt == 0u || x >= sc.atlas_w || y >= sc.atlas_h) return r;      // out of bounds reads zero
+    size_t idx = ((size_t)y * sc.atlas_w + x);
+    if (sc.atlas_fmt == 1u) {
+        const uint2 raw = reinterpret_cast<const uint2 *>(sc.atlas)[idx];        // 4 x f16
+        union { uint32_t u; _Float16 h[2]; } a, b;
+        a.u = raw.x; b.u = raw.y;
+        r.x = (float)a.h[0]; r.y = (float)a.h[1]; r.z = (float)b.h[0]; r.w = (float)b.h[1];
+    } else {
+        const float4 t = reinterpret_cast<const float4 *>(sc.atlas)[idx];
+        r.x = t.x; r.y = t.y; r.z = t.z; r.w = t.w;
+    }
+    return r;
+}
+
+// getTextureColor, pt.wgsl:112-120
+PT_DEV v4 texture_color(const DevScene &sc, const ptmi_atlas_rect &tx, float uvx, float uvy, v4 fallback) {
+    if (tx.w == 0u || tx.h == 0u) return fallback;
+    float fx = uvx - __builtin_truncf(uvx);             // uv % 1.0 (exact)
+    float fy = uvy - __builtin_truncf(uvy);
+    float ax = (float)tx.x + fx * (float)tx.w;
+    float ay = (float)tx.y + fy * (float)tx.h;
+    return atlas_load(sc, f2u(ax), f2u(ay));
+}
+
+// rayTriangleIntersect, pt.wgsl:159-226, for the closest hit only
+PT_DEV HitInfo make_hitinfo(const DevScene &sc, v3 ro, v3 rd, float t, float u, float v, uint32_t tri) {
+    HitInfo hi;
+    const ptmi_triangle &T = sc.tris[tri];
+    v3 v0 = ld3(T.v0);
+    v3 e1 = sub3(ld3(T.v1), v0), e2 = sub3(ld3(T.v2), v0);
+    hi.t = t;
+    hi.position = madd3(rd, t, ro);
+    float w = 1.0f - u - v;
+    v3 geo_n = normalize3(cross3(e1, e2));
+    v3 n_i = normalize3(lincomb3(ld3(T.n0), w, ld3(T.n1), u, ld3(T.n2), v));
+    float uvx = fma1(T.uv2[0], v, fma1(T.uv1[0], u, T.uv0[0] * w));
+    float uvy = fma1(T.uv2[1], v, fma1(T.uv1[1], u, T.uv0[1] * w));
+    hi.is_front = dot3(geo_n, rd) < 0.0f;
+    uint32_t mi = T.material_index;
+    ptmi_material m;
+    if (mi < sc.n_mats) m = sc.mats[mi];
+    else __builtin_memset(&m, 0, sizeof m);
+    v4 one; one.x = one.y = one.z = one.w = 1.0f;
+    v4 alb = texture_color(sc, m.albedo_map, uvx, uvy, one);
+    hi.albedo = mk3(alb.x * m.base_color[0], alb.y * m.base_color[1], alb.z * m.base_color[2]);
+    v4 pbr = texture_color(sc, m.pbr_map, uvx, uvy, one);
+    hi.metallic = pbr.z * m.metallic;
+    hi.roughness = max1(pbr.y * m.roughness, 0.04f);
+    hi.transmission = m.transmission;
+    hi.ior = m.ior;
+    v4 em = texture_color(sc, m.emissive_map, uvx, uvy, one);
+    hi.emission = mk3(em.x * m.emission[0], em.y * m.emission[1], em.z * m.emission[2]);
+    hi.emissive_strength = m.emissive_strength;
+    v4 flat; flat.x = 0.5f; flat.y = 0.5f; flat.z = 1.0f; flat.w = 1.0f;
+    v4 nm = texture_color(sc, m.normal_map, uvx, uvy, flat);
+    if (nm.x != 0.5f || nm.y != 0.5f || nm.z != 1.0f) {
+        float du1x = T.uv1[0] - T.uv0[0], du1y = T.uv1[1] - T.uv0[1];
+        float du2x = T.uv2[0] - T.uv0[0], du2y = T.uv2[1] - T.uv0[1];
+        float rr = 1.0f / fma1(du1x, du2y, -(du1y * du2x));
+        v3 tg = mk3(fma1(e1.x, du2y, -(e2.x * du1y)) * rr, fma1(e1.y, du2y, -(e2.y * du1y)) * rr,
+                    fma1(e1.z, du2y, -(e2.z * du1y)) * rr);
+        tg = normalize3(tg);
+        v3 N = n_i;
+        v3 Tn = normalize3(madd3(N, -dot3(N, tg), tg));
+        v3 Bn = normalize3(cross3(N, Tn));
+        float tx = nm.x * 2.0f - 1.0f, ty = nm.y * 2.0f - 1.0f, tz = nm.z * 2.0f - 1.0f;
+        hi.normal = normalize3(lincomb3(Tn, tx, Bn, ty, N, tz));
+    } else {
+        hi.normal = n_i;
+    }
+    return hi;
+}
+
+PT_DEV v3 random_cosine_direction(uint32_t &rng) {             // pt.wgsl:299-307
+    float r1 = rng_f(rng), r2 = rng_f(rng);
+    float z = __builtin_sqrtf(1.0f - r2);
+    float phi = (2.0f * PT_PI) * r1;
+    float sp, cp; sincos1(phi, sp, cp);
+    float sr = __builtin_sqrtf(r2);
+    return mk3(cp * sr, sp * sr, z);
+}
+PT_DEV float distribution_ggx(v3 N, v3 H, float roughness) {   // pt.wgsl:316-325
+    float a = roughness * roughness;
+    float a2 = a * a;
+    float ndh = max1(dot3(N, H), 0.0f);
+    float ndh2 = ndh * ndh;
+    float denom = ndh2 * (a2 - 1.0f) + 1.0f;
+    return max1(a2 / (PT_PI * denom * denom), 0.0f);
+}
+PT_DEV float geometry_schlick_ggx(float ndv, float roughness) { // pt.wgsl:328-332
+    float r = roughness + 1.0f;
+    float k = (r * r) / 8.0f;
+    return ndv / (ndv * (1.0f - k) + k);
+}
+PT_DEV float geometry_smith(v3 N, v3 V, v3 L, float roughness) { // pt.wgsl:334-340
+    float ndv = max1(dot3(N, V), 0.0f);
+    float ndl = max1(dot3(N, L), 0.0f);
+    float g2 = geometry_schlick_ggx(ndv, roughness);
+    float g1 = geometry_schlick_ggx(ndl, roughness);
+    return g1 * g2;
+}
+PT_DEV v3 fresnel_schlick(float cos_theta, v3 F0) {             // pt.wgsl:343-345
+    float p = pow5(1.0f - cos_theta);
+    return mk3(fma1(1.0f - F0.x, p, F0.x), fma1(1.0f - F0.y, p, F0.y), fma1(1.0f - F0.z, p, F0.z));
+}
+PT_DEV float reflectance(float cos_theta, float eta) {          // pt.wgsl:616-620
+    float r0 = (1.0f - eta) / (1.0f + eta);
+    r0 = r0 * r0;
+    return r0 + (1.0f - r0) * pow5(1.0f - cos_theta);
+}
+PT_DEV void construct_tbn(v3 N, v3 &T, v3 &B) {                 // pt.wgsl:624-634
+    T = mk3(1.0f, 0.0f, 0.0f);
+    if (__builtin_fabsf(N.x) > 0.9f) T = mk3(0.0f, 1.0f, 0.0f);
+    B = normalize3(cross3(N, T));
+    T = normalize3(cross3(B, N));
+}
+PT_DEV v3 sample_ggx_normal(uint32_t &rng, v3 normal, float roughness) {   // pt.wgsl:348-364
+    float r1 = rng_f(rng), r2 = rng_f(rng);
+    float a = roughness * roughness;
+    float phi = (2.0f * PT_PI) * r1;
+    float cos_t = __builtin_sqrtf((1.0f - r2) / (1.0f + (a * a - 1.0f) * r2));
+    float sin_t = __builtin_sqrtf(1.0f - cos_t * cos_t);
+    float sp, cp; sincos1(phi, sp, cp);
+    v3 T, B; construct_tbn(normal, T, B);
+    return normalize3(lincomb3(T, sin_t * cp, B, sin_t * sp, normal, cos_t));
+}
+PT_DEV float power_heuristic(float nf, float fpdf, float ng, float gpdf) { // pt.wgsl:492-496
+    float f = nf * fpdf, g = ng * gpdf;
+    return (f * f) / (f * f + g * g);
+}
+// sampleBSDF, pt.wgsl:498-546
+PT_DEV v3 sample_bsdf(uint32_t &rng, const HitInfo &h, v3 rd, bool front) {
+    v3 V = neg3(normalize3(rd));
+    float diffuse_p = (1.0f - h.metallic) * (1.0f - h.transmission);
+    float specular_p = h.metallic;
+    float r = rng_f(rng);
+    if (r < diffuse_p) {
+        v3 l = random_cosine_direction(rng);
+        v3 T, B; construct_tbn(h.normal, T, B);
+        return lincomb3(T, l.x, B, l.y, h.normal, l.z);
+    } else if (r < diffuse_p + specular_p) {
+        float rough = max1(h.roughness, 0.04f);
+        v3 N = sample_ggx_normal(rng, h.normal, rough);
+        return reflect3(neg3(V), N);
+    } else {
+        float eta = front ? 1.0f / h.ior : h.ior;
+        float rough = max1(h.roughness, 0.04f);
+        v3 N = sample_ggx_normal(rng, h.normal, rough);
+        if (!front) N = neg3(N);
+        float cos_t = dot3(N, V);
+        float sin_t = __builtin_sqrtf(1.0f - cos_t * cos_t);
+        bool cannot_refract = eta * sin_t > 1.0f;
+        float F = reflectance(__builtin_fabsf(cos_t), eta);
+        if (cannot_refract || (rng_f(rng) < F)) return reflect3(neg3(V), N);   // short-circuit: draw only if needed
+        return refract3(neg3(V), N, eta);
+    }
+}
+// evalBSDF, pt.wgsl:548-614: (f*cos, pdf)
+PT_DEV v4 eval_bsdf(const HitInfo &h, v3 normal, v3 V, v3 L, bool front) {
+    v3 H = normalize3(add3(V, L));
+    float ndl = max1(dot3(normal, L), 0.0f);
+    float ndv = max1(dot3(normal, V), 0.0f);
+    float ndh = max1(dot3(normal, H), 0.0f);
+    float vdh = max1(dot3(V, H), 0.0f);
+    v3 F0 = mk3(mix1(0.04f, h.albedo.x, h.metallic), mix1(0.04f, h.albedo.y, h.metallic),
+                mix1(0.04f, h.albedo.z, h.metallic));
+    v3 F = fresnel_schlick(vdh, F0);
+    float G = geometry_smith(normal, V, L, h.roughness);
+    float D = distribution_ggx(normal, H, h.roughness);
+    float one_m_tr = 1.0f - h.transmission;
+    v3 kD = mk3((1.0f - F.x) * one_m_tr, (1.0f - F.y) * one_m_tr, (1.0f - F.z) * one_m_tr);
+    v3 diffuse = vdiv3(mul3(kD, h.albedo), PT_PI);
+    v3 specular = vdiv3(scale3(scale3(F, G), D), max1(4.0f * ndv * ndl, PT_EPS));
+    v3 bsdf = mk3(0.0f, 0.0f, 0.0f);
+    float pdf = 0.0f;
+    if (h.transmission > 0.0f) {
+        float eta = front ? 1.0f / h.ior : h.ior;
+        float cos_t = dot3(normal, V);
+        float Ft = reflectance(__builtin_fabsf(cos_t), eta);
+        bsdf = scale3(h.albedo, 1.0f - Ft);
+        pdf = (1.0f - h.metallic) * h.transmission;
+    } else {
+        bsdf = scale3(add3(diffuse, specular), ndl);
+        float diffuse_p = (1.0f - h.metallic) * (1.0f - h.transmission);
+        float specular_p = h.metallic;
+        float diffuse_pdf = ndl / PT_PI;
+        float specular_pdf = D * ndh / (4.0f * vdh);
+        pdf = diffuse_p * diffuse_pdf + specular_p * specular_pdf;
+    }
+    v4 r; r.x = bsdf.x; r.y = bsdf.y; r.z = bsdf.z; r.w = max1(pdf, PT_EPS);
+    return r;
+}
+
+struct LightSample { v3 intensity; v3 wi; float pdf; float dist; };   // dist < 0: directional
+
+// sampleLight, pt.wgsl:374-489, without its traversal: the occlusion test is the
+// `shadow` kernel's; pdf = 0 means "no record" (the :413-415 early-out).
+PT_DEV LightSample sample_light(const DevScene &sc, uint32_t &rng, v3 hit_pos) {
+    LightSample ls;
+    ls.intensity = mk3(0.0f, 0.0f, 0.0f); ls.wi = mk3(0.0f, 0.0f, 0.0f); ls.pdf = 0.0f; ls.dist = -1.0f;
+    const uint32_t nl = sc.n_lights;
+    const ptmi_light lt = sc.lights[rng_int(rng, 0u, nl - 1u)];
+    const float inv_n = 1.0f / (float)nl;
+    if (lt.light_type == PTMI_LIGHT_DIRECTIONAL) {
+        ls.wi = normalize3(neg3(ld3(lt.position)));
+        ls.intensity = scale3(ld3(lt.color), lt.intensity);
+        ls.pdf = inv_n * 1000.0f;
+        ls.dist = -1.0f;
+    } else if (lt.light_type == PTMI_LIGHT_POINT) {
+        v3 to_l = sub3(ld3(lt.position), hit_pos);
+        float dist = length3(to_l);
+        if (dist > 100.0f) return ls;
+        ls.wi = vdiv3(to_l, dist);
+        float att = 1.0f / (dist * dist);
+        ls.intensity = scale3(scale3(ld3(lt.color), lt.intensity), att);
+        ls.pdf = inv_n * 10000.0f;
+        ls.dist = dist;
+    } else if (lt.light_type == PTMI_LIGHT_EMISSIVE) {
+        ptmi_triangle T;
+        if (lt.triangle_index < sc.n_tris) T = sc.tris[lt.triangle_index];
+        else __builtin_memset(&T, 0, sizeof T);
+        float r1 = rng_f(rng), r2 = rng_f(rng);
+        float sq = __builtin_sqrtf(r1);
+        float u = 1.0f - sq;
+        float v = r2 * sq;
+        float w = 1.0f - u - v;
+        v3 lp = lincomb3(ld3(T.v0), w, ld3(T.v1), u, ld3(T.v2), v);
+        v3 n = normalize3(lincomb3(ld3(T.n0), w, ld3(T.n1), u, ld3(T.n2), v));
+        v3 to_l = sub3(lp, hit_pos);
+        float dist = length3(to_l);
+        v3 wi = vdiv3(to_l, dist);
+        v3 e1 = sub3(ld3(T.v1), ld3(T.v0)), e2 = sub3(ld3(T.v2), ld3(T.v0));
+        float area = length3(cross3(e1, e2)) * 0.5f;
+        float cos_t = __builtin_fabsf(dot3(n, neg3(wi)));
+        ls.pdf = (inv_n * (1.0f / area)) * (dist * dist / max1(cos_t, PT_EPS));
+        ls.intensity = scale3(ld3(lt.color), lt.intensity);
+        ls.wi = wi;
+        ls.dist = dist;
+    }
+    return ls;
+}
+
+constexpr int SBLOCK = 256;
+
+__global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const uint32_t *__restrict__ queue,
+                                                  const uint32_t *__restrict__ count_ptr,
+                                                  const float4 *__restrict__ hits, DevShadow S,
+                                                  uint64_t *__restrict__ alive_mask,
+                                                  uint64_t *__restrict__ shadow_mask, ShadeParams sp) {
+    const uint32_t count = *count_ptr;
+    for (uint32_t base = blockIdx.x * SBLOCK; base < count; base += gridDim.x * SBLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        bool alive = false, shadow = false;
+        if (i < count) {
+            const uint32_t p = queue ? queue[i] : i;
+            const float4 h4 = hits[i];
+            if (!(h4.x < 0.0f)) {                                            // pt.wgsl:646: miss adds zero
+                const float4 o4 = P.O[p], d4 = P.D[p], t4 = P.T[p];
+                uint32_t rng = __float_as_uint(o4.w);
+                const v3 ro = xyz(o4), rd = xyz(d4);
+                v3 thr = xyz(t4);
+                const HitInfo hit = make_hitinfo(sc, ro, rd, h4.x, h4.y, h4.z, __float_as_uint(h4.w));
+                if (hit.emission.x > 0.0f || hit.emission.y > 0.0f || hit.emission.z > 0.0f) {   // pt.wgsl:652-658
+                    float att = 1.0f / (1.0f + hit.t * hit.t);
+                    float k = hit.emissive_strength;
+                    float4 l = P.L[p];
+                    P.L[p] = make_float4(l.x + thr.x * hit.emission.x * k * att, l.y + thr.y * hit.emission.y * k * att,
+                                         l.z + thr.z * hit.emission.z * k * att, 0.0f);
+                } else {
+                    if (sp.do_mis && sc.n_lights > 0u && hit.transmission == 0.0f && hit.is_front) {   // pt.wgsl:661
+                        LightSample ls = sample_light(sc, rng, hit.position);
+                        if (ls.pdf > 0.0f) {
+                            v3 V = neg3(normalize3(rd));
+                            v4 ev = eval_bsdf(hit, hit.normal, V, ls.wi, hit.is_front);
+                            float wmis = power_heuristic(1.0f, ls.pdf, 1.0f, ev.w);
+                            v3 direct = vdiv3(scale3(mul3(ls.intensity, mk3(ev.x, ev.y, ev.z)), wmis),
+                                              max1(ls.pdf, PT_EPS));          // pt.wgsl:674
+                            v3 contrib = mul3(thr, direct);                   // pt.wgsl:675, added by `shadow`
+                            v3 so = madd3(ls.wi, PT_EPS, hit.position);
+                            S.SO[i] = make_float4(so.x, so.y, so.z, ls.dist);
+                            S.SD[i] = make_float4(ls.wi.x, ls.wi.y, ls.wi.z, __uint_as_float(p));
+                            S.SC[i] = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
+                            shadow = true;
+                        }
+                    }
+                    v3 dir = sample_bsdf(rng, hit, rd, hit.is_front);         // pt.wgsl:680
+                    v4 ev = eval_bsdf(hit, hit.normal, neg3(normalize3(rd)), dir, hit.is_front);
+                    if (!(ev.w <= 0.0f)) {                                    // pt.wgsl:685
+                        v3 no = madd3(dir, PT_EPS, hit.position);             // pt.wgsl:691
+                        v3 nd = normalize3(dir);
+                        thr = mul3(thr, vdiv3(mk3(ev.x, ev.y, ev.z), max1(ev.w, PT_EPS)));   // pt.wgsl:696
+                        alive = true;
+                        if (sp.bounce > 2u) {                                 // pt.wgsl:699-705
+                            float pr = max1(max1(thr.x, thr.y), thr.z);
+                            if (rng_f(rng) > pr) alive = false;
+                            else thr = vdiv3(thr, pr);
+                        }
+                        if (alive && sp.bounce + 1u < sp.max_bounces) {
+                            P.O[p] = make_float4(no.x, no.y, no.z, __uint_as_float(rng));
+                            P.D[p] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+                            P.T[p] = make_float4(thr.x, thr.y, thr.z, 0.0f);
+                        }
+                    }
+                }
+            }
+        }
+        const uint64_t am = __ballot(alive), sm = __ballot(shadow);
+        if ((threadIdx.x & 63u) == 0u && i < count) {
+            alive_mask[i >> 6] = am;
+            shadow_mask[i >> 6] = sm;
+        }
+    }
+}
+
+}  // namespace
+
+void pt_launch_shade(hipStream_t s, int blocks, const DevScene &sc, DevPaths p, const uint32_t *queue,
+                     const uint32_t *count, const float4 *hits, DevShadow sh, uint64_t *alive_mask,
+                     uint64_t *shadow_mask, ShadeParams sp) {
+    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(SBLOCK), 0, s, sc, p, queue, count, hits, sh, alive_mask,
+                       shadow_mask, sp);
+}
