@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X wavefront path tracer.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): synthetic Cornell box, 1920x1080, 8 bounces, MIS on.
+One step = one ptmi_dispatch of --frames-per-step frames (default 8) over the rank's rows;
+the default K = 8 steps therefore render exactly the 64 spp of configs[1]. Scene and output
+live in HBM before the timed region starts (the C ABI copies host blobs at upload).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling over pixel rows —
+the frame is 1920 x (1080*N), rank r renders rows [1080 r, 1080 (r+1)) with no data-path
+collective (pixels and RNG streams are independent, pt.wgsl:719, :753-761); after every
+step the bands are gathered to rank 0 with one RCCL gather. value = all ranks' path
+segments / max-over-ranks time.
+
+Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel (closest-hit
+traversal `extend`) against HBM: algorithmic bytes per ray = 32 (origin+direction
+float4 pair) + 4 (queue index) + 16 (hit record) = 52 B, launch durations
+from HIP events recorded by the library on its own stream around every extend launch.
+`cpu_baseline` times the CPU oracle (oracle/, a restatement — the reference has no CPU
+path) on a bounded crop of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "wgpu-path-tracing_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+EXTEND_BYTES_PER_RAY = 32 + 4 + 16
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def pipeline_bytes_per_segment(do_mis, mean_len):
+    """SURVEY.md §8(d) re-derived for this build's records:
+    extend R 32+4 W 16; shade R 4+16+48 (O,D,T) W 48 + masks 0.25; compact R 4 W 4;
+    MIS: shadow record W 48 R 48 + radiance RMW 32; per path: raygen W 64+4, accumulate R 16 + frame RMW 32."""
+    seg = (32 + 4 + 16) + (4 + 16 + 48 + 48) + 8
+    if do_mis:
+        seg += 48 + 48 + 32
+    return seg + (68 + 48) / max(mean_len, 1e-9)
+
+
+def cpu_baseline(scene, width, height, bounces, mis, threads, target_s=12.0):
+    """Oracle on whole frames of the same camera: 1 calibration frame, then as many frames as
+    fit in about target_s seconds (at most the 64 of the workload)."""
+    from oracle_lib import Oracle
+    from ptmi import layout
+    import numpy as np
+    orc = Oracle(strict=False)
+    out = np.zeros((height, width, 4), np.float32)
+    _, st0 = orc.render(scene, layout.make_camera(width, height), 1, max_bounces=bounces, do_mis=mis, out=out,
+                        threads=threads)
+    frames = int(max(1, min(63, target_s / max(st0.seconds, 1e-3))))
+    _, st = orc.render(scene, layout.make_camera(width, height, frame_index=1), frames, max_bounces=bounces,
+                       do_mis=mis, out=out, threads=threads)
+    return {
+        "value": round(st.segments / st.seconds / 1e6, 4), "unit": "Msamples/s", "cores": int(st.threads),
+        "kind": "port",
+        "sample": f"frames 1..{frames} of the full {width}x{height} frame: {st.paths} paths, {st.segments} segments "
+                  f"in {st.seconds:.2f} s (oracle/pt_oracle.c contract build, OpenMP dynamic rows)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames-per-step", type=int, default=8)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080, help="rows per GPU")
+    ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--no-mis", action="store_true")
+    ap.add_argument("--scene", default="cornell")
+    ap.add_argument("--frames-per-batch", type=int, default=0)
+    ap.add_argument("--traversal", default="auto", choices=["auto", "global", "lds"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timing", type=int, default=2, help="library HIP-event timing level (2 = per kernel)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    from ptmi import layout, native, scenes, shard
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the path tracer has no CPU backend")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    mis = 0 if args.no_mis else 1
+    W, H = args.width, args.height * world
+    y0, y1 = shard.band(H, world, rank)
+    scene = scenes.make(args.scene)
+
+    ctx = native.Context(local_rank)
+    ctx.upload_scene(scene)
+    ctx.resize(W, H)
+    frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")       # binding 0, owned by the caller
+    ctx.bind_output_device(frame.data_ptr(), frame.numel() * 4)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    trav = {"auto": native.TRAVERSAL_AUTO, "global": native.TRAVERSAL_GLOBAL, "lds": native.TRAVERSAL_LDS}[args.traversal]
+    ctx.set_options(max_bounces=args.bounces, do_mis=mis, tile_y0=y0, tile_y1=y1,
+                    frames_per_batch=args.frames_per_batch, traversal=trav, cull=1, timing=args.timing)
+
+    fps = args.frames_per_step
+    frame_index = 0
+
+    def step():
+        nonlocal frame_index
+        ctx.dispatch(layout.make_camera(W, H, frame_index=frame_index), fps)
+        frame_index += fps
+        if world > 1:
+            shard.gather_bands(dist, frame, H, world, rank)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+
+    st = ctx.stats()
+    t = torch.tensor([dt, float(st.segments), float(st.shadow_rays), float(st.paths)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0])
+    segments, shadow_rays, paths = float(t[1]), float(t[2]), float(t[3])
+
+    if rank == 0:
+        mean_len = segments / paths
+        msamples = segments / dt / 1e6
+        ext_ms = st.extend_ms / max(st.extend_launches, 1)
+        ext_gbs = (st.segments * EXTEND_BYTES_PER_RAY / 1e9) / (st.extend_ms / 1e3) if st.extend_ms > 0 else None
+        b_seg = pipeline_bytes_per_segment(mis, mean_len)
+        out = {
+            "metric": "Msamples/s (rays x bounces / s)", "value": round(msamples, 3), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"{args.scene} {W}x{args.height} per GPU, {args.steps * fps} spp, {args.bounces} bounces, "
+                            f"MIS {'on' if mis else 'off'} (BASELINE.json configs[1]); frame {W}x{H}",
+                "frames_per_step": fps, "frames_per_batch": int(st.frames_per_batch_used),
+                "traversal": "lds" if st.traversal_used == native.TRAVERSAL_LDS else "global",
+                "triangles": int(len(scene.tris)), "bvh_nodes": int(len(scene.nodes)), "parallelism": f"rows x{world}",
+            },
+            "segments": int(segments), "shadow_rays": int(shadow_rays), "paths": int(paths),
+            "mean_path_length": round(mean_len, 4),
+            "nominal_msamples": round(paths * args.bounces / dt / 1e6, 3),
+            "gpu_ms_rank0": round(st.gpu_ms, 3),
+            "kernel_ms_rank0": {"extend": round(st.extend_ms, 3), "shade": round(st.shade_ms, 3),
+                                "shadow": round(st.shadow_ms, 3)},
+            "roofline": {
+                "bound": "hbm", "kernel": "extend (closest-hit BVH traversal)",
+                "achieved": None if ext_gbs is None else round(ext_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": None if ext_gbs is None else round(ext_gbs / HBM_PEAK_GBS, 6),
+                "traffic": None,
+                "bytes_per_unit": EXTEND_BYTES_PER_RAY, "units_per_launch": round(st.segments / max(st.extend_launches, 1), 1),
+                "avg_launch_ms": round(ext_ms, 4), "launches": int(st.extend_launches),
+                "pipeline_bytes_per_segment": round(b_seg, 1),
+                "pipeline_achieved": round(msamples * 1e6 * b_seg / 1e9, 3),
+                "pipeline_frac": round(msamples * 1e6 * b_seg / 1e9 / HBM_PEAK_GBS, 6),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, W, H, args.bounces, mis, min(16, os.cpu_count() or 1))
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,64 +72,90 @@ __global__ __launch_bounds__(BLOCK) void k_raygen_list(ptmi_camera cam, uint32_t
 }
 
 // ---- ordered compaction ------------------------------------------------------
-// Phase 1 (one 1024-thread workgroup): exclusive prefix of popcount(alive word) over the
-// ceil(count/64) ballot words written by `shade`; also totals the statistics.
-constexpr int SCAN_BLOCK = 1024;
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_masks(const uint32_t *__restrict__ count_ptr,
-                                                           const uint64_t *__restrict__ alive,
-                                                           const uint64_t *__restrict__ shadow,
-                                                           uint32_t *__restrict__ word_off,
-                                                           uint32_t *__restrict__ next_count,
-                                                           unsigned long long *__restrict__ stats, uint32_t bounce) {
-    __shared__ uint32_t part[SCAN_BLOCK];
-    __shared__ uint32_t spart[SCAN_BLOCK];
+// `shade` leaves one ballot word per 64 queue slots. A tile = 1024 words = 65536 slots,
+// one 1024-thread workgroup.
+//   k_tile_sums : per-tile popcount totals (+ the statistics counters)
+//   k_scatter   : every tile sums the totals of the tiles before it (a few hundred at most),
+//                 scans its own 1024 popcounts (wave shuffles + 16 wave totals in LDS), then each
+//                 wave walks its 64 words: word j's mask and base offset are read from lane j,
+//                 lane L keeps slot 64*w+L iff bit L is set, at base + popcount(bits below L).
+// The next queue is therefore the surviving path ids in unchanged (ascending) order, and its
+// length lands in next_count — no host round trip.
+constexpr int TILE_WORDS = 1024;
+
+__global__ __launch_bounds__(TILE_WORDS) void k_tile_sums(const uint32_t *__restrict__ count_ptr,
+                                                          const uint64_t *__restrict__ alive,
+                                                          const uint64_t *__restrict__ shadow,
+                                                          uint32_t *__restrict__ tile_sums,
+                                                          unsigned long long *__restrict__ stats, uint32_t bounce) {
+    __shared__ uint32_t wsum[16], wssum[16];
     const uint32_t count = *count_ptr;
     const uint32_t nwords = (count + 63u) >> 6;
-    const uint32_t per = (nwords + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    const uint32_t w0 = threadIdx.x * per;
-    const uint32_t w1 = w0 + per < nwords ? w0 + per : nwords;
-    uint32_t sum = 0, ssum = 0;
-    for (uint32_t w = w0; w < w1; w++) {
-        sum += (uint32_t)__popcll(alive[w]);
-        if (shadow) ssum += (uint32_t)__popcll(shadow[w]);
-    }
-    part[threadIdx.x] = sum; spart[threadIdx.x] = ssum;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { stats[0] += count; stats[8 + bounce] += count; }
+    if (blockIdx.x * TILE_WORDS >= nwords) return;
+    const uint32_t w = blockIdx.x * TILE_WORDS + threadIdx.x;
+    uint32_t c = 0, sc = 0;
+    if (w < nwords) { c = (uint32_t)__popcll(alive[w]); if (shadow) sc = (uint32_t)__popcll(shadow[w]); }
+    for (int off = 32; off > 0; off >>= 1) { c += __shfl_down(c, off); sc += __shfl_down(sc, off); }
+    if ((threadIdx.x & 63u) == 0u) { wsum[threadIdx.x >> 6] = c; wssum[threadIdx.x >> 6] = sc; }
     __syncthreads();
-    // Hillis-Steele inclusive scan over the 1024 partial sums
-    for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
-        uint32_t v = threadIdx.x >= (uint32_t)off ? part[threadIdx.x - off] : 0u;
-        uint32_t sv = threadIdx.x >= (uint32_t)off ? spart[threadIdx.x - off] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += v; spart[threadIdx.x] += sv;
-        __syncthreads();
-    }
-    uint32_t run = part[threadIdx.x] - sum;
-    for (uint32_t w = w0; w < w1; w++) {
-        word_off[w] = run;
-        run += (uint32_t)__popcll(alive[w]);
-    }
-    if (threadIdx.x == SCAN_BLOCK - 1) {
-        *next_count = part[threadIdx.x];
-        stats[0] += count;                       // segments
-        stats[1] += spart[threadIdx.x];          // shadow rays
-        stats[8 + bounce] += count;              // segments by bounce
+    if (threadIdx.x == 0) {
+        uint32_t t = 0, ts = 0;
+        for (int i = 0; i < 16; i++) { t += wsum[i]; ts += wssum[i]; }
+        tile_sums[blockIdx.x] = t;
+        if (ts) atomicAdd(&stats[1], (unsigned long long)ts);          // shadow rays (integer: order-free)
     }
 }
 
-// Phase 2: lane j of ballot word w keeps its path iff bit j is set; its slot in the next
-// queue is word_off[w] + popcount(bits below j). Queue order (ascending path id) is preserved.
-__global__ __launch_bounds__(BLOCK) void k_scatter(const uint32_t *__restrict__ count_ptr,
-                                                   const uint32_t *__restrict__ queue,
-                                                   const uint64_t *__restrict__ alive,
-                                                   const uint32_t *__restrict__ word_off,
-                                                   uint32_t *__restrict__ next_queue) {
+__global__ __launch_bounds__(TILE_WORDS) void k_scatter(const uint32_t *__restrict__ count_ptr,
+                                                        const uint32_t *__restrict__ queue,
+                                                        const uint64_t *__restrict__ alive,
+                                                        const uint32_t *__restrict__ tile_sums,
+                                                        uint32_t *__restrict__ next_queue,
+                                                        uint32_t *__restrict__ next_count) {
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t tile_base;
     const uint32_t count = *count_ptr;
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
-        const uint64_t m = alive[i >> 6];
-        const uint32_t lane = i & 63u;
-        if ((m >> lane) & 1ull) {
-            uint32_t below = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            next_queue[word_off[i >> 6] + below] = queue ? queue[i] : i;
+    const uint32_t nwords = (count + 63u) >> 6;
+    const uint32_t ntiles = (nwords + TILE_WORDS - 1) / TILE_WORDS;
+    if (blockIdx.x >= ntiles) {
+        if (ntiles == 0 && blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0;
+        return;
+    }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // totals of the tiles in front of this one
+    uint32_t pre = 0;
+    for (uint32_t t = threadIdx.x; t < blockIdx.x; t += TILE_WORDS) pre += tile_sums[t];
+    for (int off = 32; off > 0; off >>= 1) pre += __shfl_down(pre, off);
+    if (lane == 0) wtot[wave] = pre;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t t = 0; for (int i = 0; i < 16; i++) t += wtot[i]; tile_base = t; }
+    __syncthreads();
+    const uint32_t base0 = tile_base;
+    __syncthreads();
+    // exclusive scan of this tile's 1024 popcounts
+    const uint32_t w = blockIdx.x * TILE_WORDS + threadIdx.x;
+    const uint64_t m = w < nwords ? alive[w] : 0ull;
+    const uint32_t c = (uint32_t)__popcll(m);
+    uint32_t inc = c;
+    for (int off = 1; off < 64; off <<= 1) { uint32_t v = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += v; }
+    if (lane == 63u) wtot[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t i = 0; i < wave; i++) wbase += wtot[i];
+    const uint32_t my_off = base0 + wbase + inc - c;                  // offset of this lane's word
+    if (blockIdx.x == ntiles - 1 && threadIdx.x == TILE_WORDS - 1) *next_count = my_off + c;
+    // cooperative scatter: the wave walks its 64 words
+    const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
+    const uint32_t w0 = blockIdx.x * TILE_WORDS + wave * 64u;
+    for (uint32_t j = 0; j < 64u; j++) {
+        const uint32_t jlo = __shfl(mlo, (int)j), jhi = __shfl(mhi, (int)j), jbase = __shfl(my_off, (int)j);
+        const uint64_t jm = ((uint64_t)jhi << 32) | jlo;
+        if (jm == 0ull) continue;
+        if ((jm >> lane) & 1ull) {
+            const uint32_t below = (uint32_t)__popcll(jm & ((1ull << lane) - 1ull));
+            const uint32_t slot = (w0 + j) * 64u + lane;
+            next_queue[jbase + below] = queue ? queue[slot] : slot;
         }
     }
 }
@@ -187,15 +213,15 @@ void pt_launch_raygen_list(hipStream_t s, const ptmi_camera &cam, uint32_t n, co
                            const uint32_t *ys, const uint32_t *frames, DevPaths p) {
     hipLaunchKernelGGL(k_raygen_list, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, cam, n, xs, ys, frames, p);
 }
-void pt_launch_compact(hipStream_t s, int blocks, const uint32_t *queue, const uint32_t *count,
-                       const uint64_t *alive_mask, const uint64_t *shadow_mask, uint32_t *word_offsets,
+void pt_launch_compact(hipStream_t s, int tiles, const uint32_t *queue, const uint32_t *count,
+                       const uint64_t *alive_mask, const uint64_t *shadow_mask, uint32_t *tile_sums,
                        uint32_t *next_queue, uint32_t *next_count, unsigned long long *stats, uint32_t bounce,
                        int do_scatter) {
-    hipLaunchKernelGGL(k_scan_masks, dim3(1), dim3(SCAN_BLOCK), 0, s, count, alive_mask, shadow_mask, word_offsets,
-                       next_count, stats, bounce);
+    hipLaunchKernelGGL(k_tile_sums, dim3(tiles), dim3(TILE_WORDS), 0, s, count, alive_mask, shadow_mask, tile_sums,
+                       stats, bounce);
     if (do_scatter)
-        hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(BLOCK), 0, s, count, queue, alive_mask, word_offsets,
-                           next_queue);
+        hipLaunchKernelGGL(k_scatter, dim3(tiles), dim3(TILE_WORDS), 0, s, count, queue, alive_mask, tile_sums,
+                           next_queue, next_count);
 }
 void pt_launch_accumulate(hipStream_t s, int blocks, DevBand band, uint32_t frame0, uint32_t n_frames,
                           const float4 *L, float4 *out) {

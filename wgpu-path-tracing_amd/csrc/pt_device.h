@@ -70,8 +70,9 @@ void pt_launch_shade(hipStream_t s, int blocks, const DevScene &sc, DevPaths p, 
                      const uint32_t *count, const float4 *hits, DevShadow sh, uint64_t *alive_mask,
                      uint64_t *shadow_mask, ShadeParams sp);
 // ordered stream compaction of the survivors: masks -> next queue + its count, plus statistics
-void pt_launch_compact(hipStream_t s, int blocks, const uint32_t *queue, const uint32_t *count,
-                       const uint64_t *alive_mask, const uint64_t *shadow_mask, uint32_t *word_offsets,
+// (tiles = ceil(capacity / 65536): one 1024-thread workgroup per 1024 ballot words)
+void pt_launch_compact(hipStream_t s, int tiles, const uint32_t *queue, const uint32_t *count,
+                       const uint64_t *alive_mask, const uint64_t *shadow_mask, uint32_t *tile_sums,
                        uint32_t *next_queue, uint32_t *next_count, unsigned long long *stats, uint32_t bounce,
                        int do_scatter);
 void pt_launch_accumulate(hipStream_t s, int blocks, DevBand band, uint32_t frame0, uint32_t n_frames,

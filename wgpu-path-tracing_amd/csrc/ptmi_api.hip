@@ -418,7 +418,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
                     pt_launch_shadow(c->stream, blocks, cfg, c->sc, c->paths, c->sh, c->shadowm, &c->counts[b], nullptr);
                 }
                 const bool last = b + 1 == maxb;
-                pt_launch_compact(c->stream, blocks, c->queue[cur], &c->counts[b], c->alive,
+                pt_launch_compact(c->stream, (int)(c->cap / 65536 + 1), c->queue[cur], &c->counts[b], c->alive,
                                   (c->opt.do_mis && c->sc.n_lights > 0) ? c->shadowm : nullptr, c->word_off,
                                   c->queue[cur ^ 1], &c->counts[b + 1], c->d_stats, b, last ? 0 : 1);
                 cur ^= 1;

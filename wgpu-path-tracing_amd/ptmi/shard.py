@@ -1,0 +1,42 @@
+"""Pixel-row sharding across the GPUs of one node.
+
+The reference renders on one device; pixels are independent (one thread per pixel,
+src/shader/pt.wgsl:753-761) and the RNG is seeded per (x, y, frame)
+(src/shader/random.wgsl:3-5), so a frame split into contiguous row bands is
+bit-identical to the unsplit frame. Each rank renders its band with tile_y0/tile_y1
+(include/ptmi.h) — no collective on the data path — and the accumulated bands are
+concatenated on rank 0 with ONE gather (RCCL over xGMI on GPUs, gloo in CPU tests).
+"""
+
+
+def band(height, world, rank):
+    """Rows [y0, y1) of rank `rank`: contiguous, in rank order, sizes differ by at most one."""
+    if not (0 <= rank < world) or height < world:
+        raise ValueError(f"cannot split {height} rows over {world} ranks (rank {rank})")
+    return rank * height // world, (rank + 1) * height // world
+
+
+def gather_bands(dist, frame, height, world, rank, dst=0):
+    """frame: (height, width, 4) tensor, on every rank holding valid rows only in that rank's band.
+    After the call rank `dst` holds the complete frame. Works with any torch.distributed backend."""
+    if world == 1:
+        return frame
+    bands = [band(height, world, r) for r in range(world)]
+    sizes = {y1 - y0 for y0, y1 in bands}
+    y0, y1 = bands[rank]
+    if len(sizes) == 1:
+        # equal bands: gather straight into row views of the destination frame (concatenation)
+        gl = [frame[a:b] for a, b in bands] if rank == dst else None
+        dist.gather(frame[y0:y1], gl, dst=dst)
+        return frame
+    hmax = max(sizes)
+    import torch
+    send = torch.zeros((hmax,) + tuple(frame.shape[1:]), dtype=frame.dtype, device=frame.device)
+    send[: y1 - y0] = frame[y0:y1]
+    gl = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, gl, dst=dst)
+    if rank == dst:
+        for r, (a, b) in enumerate(bands):
+            if r != dst:
+                frame[a:b] = gl[r][: b - a]
+    return frame
