@@ -1,0 +1,80 @@
+"""The C-ABI shared library: loads, exports every symbol include/ptmi.h declares, and — on a
+machine without a GPU — refuses to create a context (no CPU fallback behind the product ABI)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "wgpu-path-tracing_amd")
+LIB = os.path.join(PKG, "lib", "libptmi.so")
+
+
+def declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ptmi_[a-z_0-9]+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        subprocess.check_call(["make", "-C", PKG, "all"], stdout=subprocess.DEVNULL)
+    return ctypes.CDLL(LIB)
+
+
+def test_header_symbols_exported(lib):
+    names = declared("ptmi.h")
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ptmi.h but not exported by libptmi.so"
+    from ptmi import native
+    assert sorted(native.EXPORTS) == names
+
+
+def test_scene_header_symbols_exported():
+    from ptmi import scene_host
+    L = scene_host.lib()
+    for n in declared("ptmi_scene.h"):
+        assert hasattr(L, n)
+
+
+def test_abi_version_and_struct_sizes(lib):
+    from ptmi import native
+    assert lib.ptmi_abi_version() == 1
+    assert ctypes.sizeof(native.Options) == 16 * 4
+    # ptmi_stats: 5 + 64 u64, 2 f64 + u64 + 2 f64, 4 u32
+    assert ctypes.sizeof(native.Stats) == (5 + 64) * 8 + 5 * 8 + 16
+
+
+def test_no_gpu_means_no_context(lib):
+    """Without a device the product path must fail loudly, not fall back."""
+    lib.ptmi_last_error.restype = ctypes.c_char_p
+    ctx = ctypes.c_void_p()
+    rc = lib.ptmi_create(0, ctypes.byref(ctx))
+    if rc == 0:                                     # running on a GPU box: fine, clean up
+        lib.ptmi_destroy(ctx)
+        pytest.skip("a GPU is present")
+    assert rc == -2 and not ctx.value
+    assert b"no CPU backend" in lib.ptmi_last_error(None)
+    from ptmi import native
+    with pytest.raises(native.PtmiError):
+        native.Context(0)
+
+
+def test_product_does_not_reference_the_oracle():
+    """Nothing under the product package may import, link or name the oracle."""
+    bad = []
+    for dp, _, files in os.walk(PKG):
+        if os.sep + "lib" in dp or "node_modules" in dp:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".c", ".js", ".ts", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                if re.search(r"pt_oracle|oracle_lib|oracle/", txt):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
+    out = subprocess.run(["ldd", LIB], capture_output=True, text=True).stdout
+    assert "oracle" not in out

@@ -1,0 +1,73 @@
+"""Multi-GPU path on CPU: row-band partition + the single gather, exercised with
+torch.distributed's gloo backend at world_size 2 (the oracle stands in for the renderer —
+the collective logic under test is ptmi/shard.py, the same code bench.py runs over RCCL)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from ptmi import shard
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_band_partition():
+    for H, N in ((1080, 1), (1080, 2), (1080, 8), (2160, 8), (17, 4), (8, 8)):
+        bands = [shard.band(H, N, r) for r in range(N)]
+        assert bands[0][0] == 0 and bands[-1][1] == H
+        assert all(bands[i][1] == bands[i + 1][0] for i in range(N - 1))
+        sizes = [b - a for a, b in bands]
+        assert max(sizes) - min(sizes) <= 1 and min(sizes) >= 1
+    with pytest.raises(ValueError):
+        shard.band(3, 4, 0)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, H, W, frames, q):
+    sys.path.insert(0, os.path.join(ROOT, "wgpu-path-tracing_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from oracle_lib import Oracle
+    from ptmi import layout, scenes, shard as sh
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc = scenes.make("cornell")
+        cam = layout.make_camera(W, H)
+        y0, y1 = sh.band(H, world, rank)
+        frame = np.zeros((H, W, 4), np.float32)
+        Oracle().render(sc, cam, frames, out=frame, y0=y0, y1=y1, threads=2)      # this rank's rows only
+        assert not frame[:y0].any() and not frame[y1:].any()
+        t = torch.from_numpy(frame)
+        sh.gather_bands(dist, t, H, world, rank)
+        dist.barrier()
+        if rank == 0:
+            full, _ = Oracle().render(sc, cam, frames, threads=2)
+            q.put(bool(np.array_equal(t.numpy().view(np.uint32), full.view(np.uint32))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H", [32, 33])                  # equal bands (zero-copy views) and ragged bands (padded)
+def test_two_rank_gloo_gather_equals_single_render(H):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, H, 40, 2, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) is True
