@@ -1,0 +1,279 @@
+/*
+ * ptmi_napi.c — thin N-API (Node >= 12, N-API 4) addon over the C ABI of include/ptmi.h.
+ *
+ * One JS function per C function; scene / camera blobs travel as ArrayBuffers (or typed-array
+ * views) in the exact WGSL layouts the reference writes with device.queue.writeBuffer
+ * (src/renderer/renderer.ts:242-355, :403-413). A non-zero ptmi status becomes a JS Error
+ * carrying ptmi_last_error(). No rendering logic lives here.
+ *
+ * build: oracle-free, see Makefile next to this file
+ *   gcc -shared -fPIC -I/usr/include/node -I../../../include ptmi_napi.c -L../../lib -lptmi
+ */
+#define NAPI_VERSION 4
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "ptmi.h"
+
+#define NAPI_OK(env, call)                                                        \
+    do {                                                                          \
+        if ((call) != napi_ok) {                                                  \
+            napi_throw_error((env), NULL, "N-API call failed: " #call);           \
+            return NULL;                                                          \
+        }                                                                         \
+    } while (0)
+
+static napi_value throw_ptmi(napi_env env, ptmi_ctx *ctx, int rc, const char *what) {
+    char buf[640];
+    snprintf(buf, sizeof buf, "%s failed (%d): %s", what, rc, ptmi_last_error(ctx));
+    napi_throw_error(env, "PTMI", buf);
+    return NULL;
+}
+
+static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value *argv) {
+    size_t argc = want;
+    if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < want) {
+        napi_throw_type_error(env, NULL, "wrong number of arguments");
+        return 0;
+    }
+    return 1;
+}
+
+static ptmi_ctx *get_ctx(napi_env env, napi_value v) {
+    void *p = NULL;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
+        napi_throw_type_error(env, NULL, "expected a ptmi context handle");
+        return NULL;
+    }
+    return (ptmi_ctx *)p;
+}
+
+/* ArrayBuffer or TypedArray/DataView -> (pointer, byte length); null/undefined -> (NULL, 0) */
+static int get_bytes(napi_env env, napi_value v, void **data, size_t *len) {
+    napi_valuetype t;
+    bool is;
+    *data = NULL; *len = 0;
+    if (napi_typeof(env, v, &t) == napi_ok && (t == napi_null || t == napi_undefined)) return 1;
+    if (napi_is_arraybuffer(env, v, &is) == napi_ok && is) return napi_get_arraybuffer_info(env, v, data, len) == napi_ok;
+    if (napi_is_typedarray(env, v, &is) == napi_ok && is) {
+        napi_typedarray_type tt; size_t n; napi_value ab; size_t off;
+        if (napi_get_typedarray_info(env, v, &tt, &n, data, &ab, &off) != napi_ok) return 0;
+        static const size_t esz[] = {1, 1, 1, 2, 2, 4, 4, 4, 8, 8, 8};
+        *len = n * esz[tt];
+        return 1;
+    }
+    if (napi_is_dataview(env, v, &is) == napi_ok && is) {
+        napi_value ab; size_t off;
+        return napi_get_dataview_info(env, v, len, data, &ab, &off) == napi_ok;
+    }
+    napi_throw_type_error(env, NULL, "expected an ArrayBuffer or a typed array");
+    return 0;
+}
+
+static uint32_t get_u32_prop(napi_env env, napi_value obj, const char *name, uint32_t dflt) {
+    napi_value v; bool has = false; uint32_t out = dflt;
+    if (napi_has_named_property(env, obj, name, &has) == napi_ok && has &&
+        napi_get_named_property(env, obj, name, &v) == napi_ok)
+        napi_get_value_uint32(env, v, &out);
+    return out;
+}
+
+static napi_value js_create(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    int32_t dev = 0;
+    NAPI_OK(env, napi_get_value_int32(env, argv[0], &dev));
+    ptmi_ctx *ctx = NULL;
+    int rc = ptmi_create(dev, &ctx);
+    if (rc) return throw_ptmi(env, NULL, rc, "ptmi_create");
+    napi_value ext;
+    NAPI_OK(env, napi_create_external(env, ctx, NULL, NULL, &ext));
+    return ext;
+}
+
+static napi_value js_destroy(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    ptmi_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    ptmi_destroy(ctx);
+    return NULL;
+}
+
+static napi_value js_upload_scene(napi_env env, napi_callback_info info) {
+    napi_value argv[5];
+    if (!get_args(env, info, 5, argv)) return NULL;
+    ptmi_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    void *p[4]; size_t n[4];
+    static const size_t stride[4] = {sizeof(ptmi_triangle), sizeof(ptmi_material), sizeof(ptmi_bvh_node), sizeof(ptmi_light)};
+    for (int i = 0; i < 4; i++) {
+        if (!get_bytes(env, argv[1 + i], &p[i], &n[i])) return NULL;
+        if (n[i] % stride[i]) { napi_throw_range_error(env, NULL, "blob length is not a multiple of its element size"); return NULL; }
+    }
+    int rc = ptmi_upload_scene(ctx, (const ptmi_triangle *)p[0], (uint32_t)(n[0] / stride[0]),
+                               (const ptmi_material *)p[1], (uint32_t)(n[1] / stride[1]),
+                               (const ptmi_bvh_node *)p[2], (uint32_t)(n[2] / stride[2]),
+                               (const ptmi_light *)p[3], (uint32_t)(n[3] / stride[3]));
+    if (rc) return throw_ptmi(env, ctx, rc, "ptmi_upload_scene");
+    return NULL;
+}
+
+static napi_value js_upload_atlas(napi_env env, napi_callback_info info) {
+    napi_value argv[5];
+    if (!get_args(env, info, 5, argv)) return NULL;
+    ptmi_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    void *p; size_t n; uint32_t w = 0, h = 0; int32_t fmt = 0;
+    if (!get_bytes(env, argv[1], &p, &n)) return NULL;
+    napi_get_value_uint32(env, argv[2], &w); napi_get_value_uint32(env, argv[3], &h); napi_get_value_int32(env, argv[4], &fmt);
+    if (p && n < (size_t)w * h * (fmt == PTMI_ATLAS_RGBA16F ? 8 : 16)) { napi_throw_range_error(env, NULL, "atlas buffer too small"); return NULL; }
+    int rc = ptmi_upload_atlas(ctx, p, w, h, fmt);
+    if (rc) return throw_ptmi(env, ctx, rc, "ptmi_upload_atlas");
+    return NULL;
+}
+
+static napi_value js_resize(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return NULL;
+    ptmi_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    uint32_t w = 0, h = 0;
+    napi_get_value_uint32(env, argv[1], &w); napi_get_value_uint32(env, argv[2], &h);
+    int rc = ptmi_resize(ctx, w, h);
+    if (rc) return throw_ptmi(env, ctx, rc, "ptmi_resize");
+    return NULL;
+}
+
+static napi_value js_set_options(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return NULL;
+    ptmi_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    ptmi_options o;
+    ptmi_get_options(ctx, &o);
+    o.max_bounces = get_u32_prop(env, argv[1], "maxBounces", o.max_bounces);
+    o.do_mis = get_u32_prop(env, argv[1], "doMis", o.do_mis);
+    o.tile_y0 = get_u32_prop(env, argv[1], "tileY0", o.tile_y0);
+    o.tile_y1 = get_u32_prop(env, argv[1], "tileY1", o.tile_y1);
+    o.frames_per_batch = get_u32_prop(env, argv[1], "framesPerBatch", o.frames_per_batch);
+    o.traversal = get_u32_prop(env, argv[1], "traversal", o.traversal);
+    o.cull = get_u32_prop(env, argv[1], "cull", o.cull);
+    o.timing = get_u32_prop(env, argv[1], "timing", o.timing);
+    int rc = ptmi_set_options(ctx, &o);
+    if (rc) return throw_ptmi(env, ctx, rc, "ptmi_set_options");
+    return NULL;
+}
+
+static napi_value js_dispatch(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return NULL;
+    ptmi_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    void *p; size_t n; uint32_t frames = 1;
+    if (!get_bytes(env, argv[1], &p, &n)) return NULL;
+    if (!p || n != sizeof(ptmi_camera)) { napi_throw_range_error(env, NULL, "camera blob must be 96 bytes"); return NULL; }
+    napi_get_value_uint32(env, argv[2], &frames);
+    ptmi_camera cam;
+    memcpy(&cam, p, sizeof cam);
+    int rc = ptmi_dispatch(ctx, &cam, frames);
+    if (rc) return throw_ptmi(env, ctx, rc, "ptmi_dispatch");
+    return NULL;
+}
+
+static napi_value js_synchronize(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    ptmi_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    int rc = ptmi_synchronize(ctx);
+    if (rc) return throw_ptmi(env, ctx, rc, "ptmi_synchronize");
+    return NULL;
+}
+
+/* readOutput(ctx, Float32Array dst) */
+static napi_value js_read_output(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return NULL;
+    ptmi_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    void *p; size_t n;
+    if (!get_bytes(env, argv[1], &p, &n)) return NULL;
+    int rc = ptmi_read_output(ctx, (float *)p, n / 4);
+    if (rc) return throw_ptmi(env, ctx, rc, "ptmi_read_output");
+    return argv[1];
+}
+
+static napi_value js_write_output(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return NULL;
+    ptmi_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    void *p; size_t n;
+    if (!get_bytes(env, argv[1], &p, &n)) return NULL;
+    int rc = ptmi_write_output(ctx, (const float *)p, n / 4);
+    if (rc) return throw_ptmi(env, ctx, rc, "ptmi_write_output");
+    return NULL;
+}
+
+static void set_num(napi_env env, napi_value obj, const char *k, double v) {
+    napi_value n;
+    if (napi_create_double(env, v, &n) == napi_ok) napi_set_named_property(env, obj, k, n);
+}
+
+static napi_value js_get_stats(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    ptmi_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    ptmi_stats s;
+    int rc = ptmi_get_stats(ctx, &s);
+    if (rc) return throw_ptmi(env, ctx, rc, "ptmi_get_stats");
+    napi_value o;
+    NAPI_OK(env, napi_create_object(env, &o));
+    set_num(env, o, "paths", (double)s.paths); set_num(env, o, "segments", (double)s.segments);
+    set_num(env, o, "shadowRays", (double)s.shadow_rays); set_num(env, o, "frames", (double)s.frames);
+    set_num(env, o, "dispatches", (double)s.dispatches); set_num(env, o, "gpuMs", s.gpu_ms);
+    set_num(env, o, "extendMs", s.extend_ms); set_num(env, o, "shadeMs", s.shade_ms); set_num(env, o, "shadowMs", s.shadow_ms);
+    set_num(env, o, "bvhDepth", s.bvh_depth); set_num(env, o, "traversalUsed", s.traversal_used);
+    return o;
+}
+
+static napi_value js_reset_stats(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    ptmi_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    ptmi_reset_stats(ctx);
+    return NULL;
+}
+
+static napi_value js_abi_version(napi_env env, napi_callback_info info) {
+    (void)info;
+    napi_value v;
+    NAPI_OK(env, napi_create_int32(env, ptmi_abi_version(), &v));
+    return v;
+}
+
+static napi_value init(napi_env env, napi_value exports) {
+    static const struct { const char *name; napi_callback fn; } fns[] = {
+        {"abiVersion", js_abi_version}, {"create", js_create}, {"destroy", js_destroy},
+        {"uploadScene", js_upload_scene}, {"uploadAtlas", js_upload_atlas}, {"resize", js_resize},
+        {"setOptions", js_set_options}, {"dispatch", js_dispatch}, {"synchronize", js_synchronize},
+        {"readOutput", js_read_output}, {"writeOutput", js_write_output}, {"getStats", js_get_stats},
+        {"resetStats", js_reset_stats},
+    };
+    for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
+        napi_value f;
+        if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok ||
+            napi_set_named_property(env, exports, fns[i].name, f) != napi_ok) {
+            napi_throw_error(env, NULL, "cannot register addon functions");
+            return NULL;
+        }
+    }
+    return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, init)

@@ -1,0 +1,53 @@
+// Types of the Node host. The CPU-side scene types mirror the reference's
+// src/renderer/gpu.ts:10-65 and src/renderer/bvh.ts:6-12.
+export type Vec2 = ArrayLike<number>;
+export type Vec3 = ArrayLike<number>;
+export interface AtlasTexture { x: number; y: number; w: number; h: number; }
+export interface MaterialCPU {
+  baseColor: Vec3; metallic: number; roughness: number; emission: Vec3; emissiveStrength: number;
+  ior: number; transmission: number;
+  albedoMap: AtlasTexture; normalMap: AtlasTexture; pbrMap: AtlasTexture; emissiveMap: AtlasTexture;
+}
+export interface TriangleCPU {
+  v0: Vec3; v1: Vec3; v2: Vec3; n0: Vec3; n1: Vec3; n2: Vec3; uv0: Vec2; uv1: Vec2; uv2: Vec2; materialIndex: number;
+}
+export interface CameraCPU {
+  position: number[]; forward: number[]; right: number[]; up: number[]; fov: number; aspect: number;
+  width: number; height: number; frameIndex: number; aperture: number; focusDistance: number;
+}
+export interface LightCPU { position: Vec3; lightType: number; color: Vec3; intensity: number; triangleIndex: number; }
+export interface BVHNode { aabb: { min: Vec3; max: Vec3 }; left: number; right: number; triangleOffset: number; triangleCount: number; }
+export interface SceneData { triangles: TriangleCPU[]; materials: MaterialCPU[]; bvhNodes: BVHNode[]; lights: LightCPU[]; }
+export interface SceneBlobs { triangles: ArrayBuffer; materials: ArrayBuffer; bvhNodes: ArrayBuffer; lights: ArrayBuffer; }
+export interface Atlas { data: ArrayBuffer; width: number; height: number; format: 1 | 2; }
+export interface TraceOptions {
+  maxBounces?: number; doMis?: number; tileY0?: number; tileY1?: number; framesPerBatch?: number;
+  traversal?: 0 | 1 | 2; cull?: number; timing?: number;
+}
+export interface Stats {
+  paths: number; segments: number; shadowRays: number; frames: number; dispatches: number;
+  gpuMs: number; extendMs: number; shadeMs: number; shadowMs: number; bvhDepth: number; traversalUsed: number;
+}
+export class Renderer {
+  constructor(options?: { device?: number; width?: number; height?: number; options?: TraceOptions });
+  camera: CameraCPU;
+  addOnUpdate(callback: (deltaTime: number) => void): void;
+  loadModel(model: string | SceneData | { blobs: SceneBlobs; atlas?: Atlas | null }, atlas?: Atlas): Promise<void>;
+  renderFrame(frames?: number): void;
+  start(): void;
+  stop(): void;
+  destroy(): void;
+  resize(width: number, height: number): void;
+  moveCamera(forward: number, right: number, up: number): void;
+  rotateCamera(yaw: number, pitch: number): void;
+  readOutput(): Float32Array;
+  setOptions(o: TraceOptions): void;
+  getStats(): Stats;
+}
+export function setupRenderer(options?: { device?: number; width?: number; height?: number; model?: string; autoStart?: boolean; options?: TraceOptions }): Promise<Renderer>;
+export const pack: {
+  packTriangles(t: TriangleCPU[]): ArrayBuffer; packMaterials(m: MaterialCPU[]): ArrayBuffer;
+  packBVH(n: BVHNode[]): ArrayBuffer; packLights(l: LightCPU[]): ArrayBuffer;
+  packCamera(c: CameraCPU, out?: ArrayBuffer): ArrayBuffer; packScene(s: SceneData): SceneBlobs;
+};
+export function readSceneFile(path: string): { blobs: SceneBlobs; atlas: Atlas | null };

@@ -1,0 +1,179 @@
+'use strict';
+/**
+ * renderer.js — Node host with the reference Renderer's public surface
+ * (src/renderer/renderer.ts:18-511: loadModel, start, stop, destroy, resize, moveCamera,
+ * rotateCamera, addOnUpdate, camera) whose compute pass runs on the MI355X through the
+ * N-API addon instead of WebGPU:
+ *
+ *   createBuffers + createBindGroups (renderer.ts:242-355, :368-381) -> uploadScene / uploadAtlas / resize
+ *   updateCamera                      (renderer.ts:403-413)          -> packCamera (96-byte uniform)
+ *   compute pass dispatch             (renderer.ts:421-431)          -> addon.dispatch(ctx, camera, 1)
+ *
+ * The blit pass, tweakpane stats and the DOM controller are out of scope (SURVEY.md §8).
+ * Plain JavaScript (Node >= 12: no optional chaining), typed by index.d.ts.
+ */
+var path = require('path');
+var pack = require('./pack');
+var sceneFile = require('./scene_file');
+
+var addon = null;
+function loadAddon() {
+  if (!addon) addon = require(path.join(__dirname, 'addon', 'ptmi_napi.node'));   // throws if not built
+  return addon;
+}
+
+var MAX_FRAMES = -1;                       // renderer.ts:16
+
+function Renderer(options) {
+  options = options || {};
+  this.addon = loadAddon();
+  this.ctx = this.addon.create(options.device || 0);   // throws without a gfx950 device: there is no CPU path
+  this.width = options.width || 800;
+  this.height = options.height || 600;
+  this.frameIndex = 0;
+  this.onUpdateTasks = [];
+  this.timer = null;
+  this.lastTime = 0;
+  this.sceneLoaded = false;
+  this.cameraBytes = new ArrayBuffer(pack.CAMERA_SIZE);
+  this.setupCamera();
+  this.addon.resize(this.ctx, this.width, this.height);
+  if (options.options) this.addon.setOptions(this.ctx, options.options);
+}
+
+/** renderer.ts:136-150 */
+Renderer.prototype.setupCamera = function () {
+  this.camera = {
+    position: [0, 1.0, 2.8], forward: [0, 0, -1], right: [1, 0, 0], up: [0, 1, 0],
+    fov: Math.PI / 3, aspect: this.width / this.height, width: this.width, height: this.height,
+    frameIndex: 0, focusDistance: 5.0, aperture: 0.001,
+  };
+};
+
+Renderer.prototype.addOnUpdate = function (callback) { this.onUpdateTasks.push(callback); };
+
+/**
+ * renderer.ts:130-134. `model` is a .ptscene path, {blobs, atlas} from readSceneFile, or a
+ * SceneData object (gpu.ts:60-65) which is packed here like renderer.ts:282-320 does.
+ */
+Renderer.prototype.loadModel = function (model, atlas) {
+  var self = this;
+  return new Promise(function (resolve) {
+    var blobs;
+    if (typeof model === 'string') {
+      var f = sceneFile.readSceneFile(model);
+      blobs = f.blobs; atlas = atlas || f.atlas;
+    } else if (model.blobs) {
+      blobs = model.blobs; atlas = atlas || model.atlas;
+    } else {
+      blobs = pack.packScene(model);
+    }
+    self.addon.uploadScene(self.ctx, blobs.triangles, blobs.materials, blobs.bvhNodes, blobs.lights);
+    if (atlas) self.addon.uploadAtlas(self.ctx, atlas.data, atlas.width, atlas.height, atlas.format || 1);
+    else self.addon.uploadAtlas(self.ctx, null, 0, 0, 0);
+    self.sceneLoaded = true;
+    self.resetOutputBuffer(false);
+    resolve();
+  });
+};
+
+/** renderer.ts:357-366 */
+Renderer.prototype.resetOutputBuffer = function (restart) {
+  this.frameIndex = 0;
+  this.camera.frameIndex = 0;
+  if (restart !== false && this.timer === null && this.sceneLoaded) this.start();
+};
+
+/** renderer.ts:403-413 */
+Renderer.prototype.updateCamera = function () {
+  this.camera.frameIndex = this.frameIndex;
+  pack.packCamera(this.camera, this.cameraBytes);
+};
+
+/** renderer.ts:415-454 (compute pass only). frames > 1 traces that many consecutive frames in one call. */
+Renderer.prototype.renderFrame = function (frames) {
+  frames = frames || 1;
+  this.updateCamera();
+  this.addon.dispatch(this.ctx, this.cameraBytes, frames);
+  this.frameIndex += frames;
+};
+
+/** renderer.ts:456-473 — requestAnimationFrame becomes setImmediate */
+Renderer.prototype.start = function () {
+  var self = this;
+  this.lastTime = Date.now();
+  var animate = function () {
+    var now = Date.now();
+    var dt = (now - self.lastTime) / 1000;
+    self.lastTime = now;
+    for (var i = 0; i < self.onUpdateTasks.length; i++) self.onUpdateTasks[i](dt);
+    if (MAX_FRAMES === -1 || self.frameIndex < MAX_FRAMES) self.renderFrame();
+    if (self.timer !== null) self.timer = setImmediate(animate);
+  };
+  this.timer = setImmediate(animate);
+};
+
+Renderer.prototype.stop = function () {
+  if (this.timer !== null) { clearImmediate(this.timer); this.timer = null; }
+};
+
+/** renderer.ts:482-494 */
+Renderer.prototype.destroy = function () {
+  this.stop();
+  if (this.ctx) { this.addon.destroy(this.ctx); this.ctx = null; }
+};
+
+/** renderer.ts:496-510 */
+Renderer.prototype.resize = function (width, height) {
+  this.width = width; this.height = height;
+  this.camera.aspect = width / height;
+  this.camera.width = width; this.camera.height = height;
+  this.frameIndex = 0;
+  this.addon.resize(this.ctx, width, height);
+};
+
+/** renderer.ts:152-170 */
+Renderer.prototype.moveCamera = function (forward, right, up) {
+  var c = this.camera;
+  for (var k = 0; k < 3; k++) c.position[k] += right * c.right[k] + forward * c.forward[k] + up * c.up[k];
+  this.resetOutputBuffer();
+};
+
+function normalize(v) { var l = Math.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); return [v[0] / l, v[1] / l, v[2] / l]; }
+function cross(a, b) { return [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]]; }
+
+/** renderer.ts:172-201: yaw about +Y, then the clamped pitch delta about +X */
+Renderer.prototype.rotateCamera = function (yaw, pitch) {
+  var c = this.camera;
+  var currentPitch = Math.asin(c.forward[1]);
+  var lim = (Math.PI / 2) * 0.99;
+  var newPitch = Math.max(Math.min(currentPitch + pitch, lim), -lim);
+  var dp = newPitch - currentPitch;
+  var f = c.forward;
+  var cx = Math.cos(dp), sx = Math.sin(dp);                 // v1 = Rx(dp) v
+  var v1 = [f[0], cx * f[1] - sx * f[2], sx * f[1] + cx * f[2]];
+  var cy = Math.cos(yaw), sy = Math.sin(yaw);               // v2 = Ry(yaw) v1
+  c.forward = normalize([cy * v1[0] + sy * v1[2], v1[1], -sy * v1[0] + cy * v1[2]]);
+  c.right = normalize(cross(c.forward, [0, 1, 0]));
+  c.up = normalize(cross(c.right, c.forward));
+  this.resetOutputBuffer();
+};
+
+/** Output buffer (binding 0): width*height float4, row 0 = image bottom. Synchronises. */
+Renderer.prototype.readOutput = function () {
+  var out = new Float32Array(this.width * this.height * 4);
+  this.addon.readOutput(this.ctx, out);
+  return out;
+};
+
+Renderer.prototype.setOptions = function (o) { this.addon.setOptions(this.ctx, o); };
+Renderer.prototype.getStats = function () { return this.addon.getStats(this.ctx); };
+
+/** renderer.ts:513-558 without the canvas: create, load, (optionally) start */
+function setupRenderer(options) {
+  var r = new Renderer(options);
+  if (!options || !options.model) return Promise.resolve(r);
+  return r.loadModel(options.model).then(function () { if (options.autoStart) r.start(); return r; });
+}
+
+module.exports = { Renderer: Renderer, setupRenderer: setupRenderer, pack: pack, readSceneFile: sceneFile.readSceneFile };
