@@ -805,6 +805,75 @@ int pto_trace_path(const pto_scene *s, const ptmi_camera *cam, uint32_t x, uint3
     return nl;
 }
 
+/* Analysis aid (not a parity function): work counters of an ordered two-box descent with the
+ * kernels' cull rule, per ray: out3[3i..] = wide-node steps, leaf visits, triangle tests. */
+static void ordered_counts(const pto_scene *s, ray_t r, int cull, int pop_cull, float tlim_any, uint32_t *out3) {
+    uint32_t steps = 0, leaves = 0, tris = 0;
+    out3[0] = out3[1] = out3[2] = 0;
+    if (s->n_nodes == 0) return;
+    v3 inv = V3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    if (!box_test(&s->nodes[0], r.o, r.d, inv)) return;
+    uint32_t stack[256]; float stackt[256]; int sp = 0;
+    uint32_t cur = 0; float best = INFINITY; uint32_t btri = 0xFFFFFFFFu;
+    int anyhit = tlim_any != 0.0f;                 /* tlim_any: 0 = closest hit, <0 directional, >0 distance limit */
+    float limit = (anyhit && tlim_any > 0.0f && cull) ? __builtin_fmaf(tlim_any, 1.001f, 1e-4f) : INFINITY;
+    for (;;) {
+        const ptmi_bvh_node *n = &s->nodes[cur];
+        if (n->triangle_count == 0) {
+            steps++;
+            const ptmi_bvh_node *L = &s->nodes[n->left], *R = &s->nodes[n->right];
+            float tl, tr; int hl, hr;
+            {   float t1x = (L->aabb_min[0] - r.o.x) * inv.x, t2x = (L->aabb_max[0] - r.o.x) * inv.x;
+                float t1y = (L->aabb_min[1] - r.o.y) * inv.y, t2y = (L->aabb_max[1] - r.o.y) * inv.y;
+                float t1z = (L->aabb_min[2] - r.o.z) * inv.z, t2z = (L->aabb_max[2] - r.o.z) * inv.z;
+                tl = max1(max1(min1(t1x, t2x), min1(t1y, t2y)), min1(t1z, t2z));
+                float tm = min1(min1(max1(t1x, t2x), max1(t1y, t2y)), max1(t1z, t2z));
+                hl = tm >= tl && tm >= 0.0f; }
+            {   float t1x = (R->aabb_min[0] - r.o.x) * inv.x, t2x = (R->aabb_max[0] - r.o.x) * inv.x;
+                float t1y = (R->aabb_min[1] - r.o.y) * inv.y, t2y = (R->aabb_max[1] - r.o.y) * inv.y;
+                float t1z = (R->aabb_min[2] - r.o.z) * inv.z, t2z = (R->aabb_max[2] - r.o.z) * inv.z;
+                tr = max1(max1(min1(t1x, t2x), min1(t1y, t2y)), min1(t1z, t2z));
+                float tm = min1(min1(max1(t1x, t2x), max1(t1y, t2y)), max1(t1z, t2z));
+                hr = tm >= tr && tm >= 0.0f; }
+            if (cull) { hl = hl && !(tl > limit); hr = hr && !(tr > limit); }
+            if (hl && hr) {
+                int lf = tl <= tr;
+                stack[sp] = lf ? n->right : n->left; stackt[sp] = lf ? tr : tl; sp++;
+                cur = lf ? n->left : n->right; continue;
+            }
+            if (hl) { cur = n->left; continue; }
+            if (hr) { cur = n->right; continue; }
+        } else {
+            leaves++;
+            int done = 0;
+            for (uint32_t k = 0; k < n->triangle_count; k++) {
+                uint32_t ti = n->triangle_offset + k; float u, v;
+                tris++;
+                float t = tri_test(&s->tris[ti], r.o, r.d, &u, &v);
+                if (t > 0.0f) {
+                    if (anyhit) { if (tlim_any < 0.0f || t < tlim_any) { done = 1; break; } }
+                    else if (t < best || (t == best && ti < btri)) { best = t; btri = ti; if (cull) limit = __builtin_fmaf(t, 1.001f, 1e-4f); }
+                }
+            }
+            if (done) break;
+        }
+        for (;;) {
+            if (sp == 0) { out3[0] = steps; out3[1] = leaves; out3[2] = tris; return; }
+            sp--; cur = stack[sp];
+            if (!(pop_cull && cull && stackt[sp] > limit)) break;
+        }
+    }
+    out3[0] = steps; out3[1] = leaves; out3[2] = tris;
+}
+void pto_ordered_counts(const pto_scene *s, uint32_t n, const float *o3, const float *d3, const float *tlim,
+                        int cull, int pop_cull, uint32_t *out3) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; i++) {
+        ray_t r = { ld3(o3 + 3 * i), ld3(d3 + 3 * i) };
+        ordered_counts(s, r, cull, pop_cull, tlim ? tlim[i] : 0.0f, out3 + 3 * i);
+    }
+}
+
 /* arithmetic-contract probe, same op codes as ptmi_debug_math (include/ptmi.h) */
 void pto_math(int op, uint32_t n, const float *a, const float *b, const float *c, float *out) {
     for (uint32_t i = 0; i < n; i++) {

@@ -87,6 +87,7 @@ __global__ __launch_bounds__(TILE_WORDS) void k_tile_sums(const uint32_t *__rest
                                                           const uint64_t *__restrict__ alive,
                                                           const uint64_t *__restrict__ shadow,
                                                           uint32_t *__restrict__ tile_sums,
+                                                          uint32_t *__restrict__ shadow_tile_sums,
                                                           unsigned long long *__restrict__ stats, uint32_t bounce) {
     __shared__ uint32_t wsum[16], wssum[16];
     const uint32_t count = *count_ptr;
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(TILE_WORDS) void k_tile_sums(const uint32_t *__rest
         uint32_t t = 0, ts = 0;
         for (int i = 0; i < 16; i++) { t += wsum[i]; ts += wssum[i]; }
         tile_sums[blockIdx.x] = t;
+        shadow_tile_sums[blockIdx.x] = ts;
         if (ts) atomicAdd(&stats[1], (unsigned long long)ts);          // shadow rays (integer: order-free)
     }
 }
@@ -215,13 +217,17 @@ void pt_launch_raygen_list(hipStream_t s, const ptmi_camera &cam, uint32_t n, co
 }
 void pt_launch_compact(hipStream_t s, int tiles, const uint32_t *queue, const uint32_t *count,
                        const uint64_t *alive_mask, const uint64_t *shadow_mask, uint32_t *tile_sums,
-                       uint32_t *next_queue, uint32_t *next_count, unsigned long long *stats, uint32_t bounce,
-                       int do_scatter) {
+                       uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_queue, uint32_t *shadow_count,
+                       unsigned long long *stats, uint32_t bounce, int do_scatter) {
+    uint32_t *shadow_sums = tile_sums + tiles;
     hipLaunchKernelGGL(k_tile_sums, dim3(tiles), dim3(TILE_WORDS), 0, s, count, alive_mask, shadow_mask, tile_sums,
-                       stats, bounce);
+                       shadow_sums, stats, bounce);
     if (do_scatter)
         hipLaunchKernelGGL(k_scatter, dim3(tiles), dim3(TILE_WORDS), 0, s, count, queue, alive_mask, tile_sums,
                            next_queue, next_count);
+    if (shadow_mask)    // slots (not path ids) of the emitted shadow records, ascending
+        hipLaunchKernelGGL(k_scatter, dim3(tiles), dim3(TILE_WORDS), 0, s, count, (const uint32_t *)nullptr,
+                           shadow_mask, shadow_sums, shadow_queue, shadow_count);
 }
 void pt_launch_accumulate(hipStream_t s, int blocks, DevBand band, uint32_t frame0, uint32_t n_frames,
                           const float4 *L, float4 *out) {

@@ -64,8 +64,9 @@ void pt_launch_raygen_list(hipStream_t s, const ptmi_camera &cam, uint32_t n, co
                            const uint32_t *ys, const uint32_t *frames, DevPaths p);
 void pt_launch_extend(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, DevPaths p,
                       const uint32_t *queue, const uint32_t *count, float4 *hits);
+// shadow_queue: slots of the shadow records to trace (NULL = slots 0..count-1), count = their number
 void pt_launch_shadow(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, DevPaths p,
-                      DevShadow sh, const uint64_t *shadow_mask, const uint32_t *count, uint8_t *occluded_out);
+                      DevShadow sh, const uint32_t *shadow_queue, const uint32_t *count, uint8_t *occluded_out);
 void pt_launch_shade(hipStream_t s, int blocks, const DevScene &sc, DevPaths p, const uint32_t *queue,
                      const uint32_t *count, const float4 *hits, DevShadow sh, uint64_t *alive_mask,
                      uint64_t *shadow_mask, ShadeParams sp);
@@ -73,8 +74,8 @@ void pt_launch_shade(hipStream_t s, int blocks, const DevScene &sc, DevPaths p, 
 // (tiles = ceil(capacity / 65536): one 1024-thread workgroup per 1024 ballot words)
 void pt_launch_compact(hipStream_t s, int tiles, const uint32_t *queue, const uint32_t *count,
                        const uint64_t *alive_mask, const uint64_t *shadow_mask, uint32_t *tile_sums,
-                       uint32_t *next_queue, uint32_t *next_count, unsigned long long *stats, uint32_t bounce,
-                       int do_scatter);
+                       uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_queue, uint32_t *shadow_count,
+                       unsigned long long *stats, uint32_t bounce, int do_scatter);
 void pt_launch_accumulate(hipStream_t s, int blocks, DevBand band, uint32_t frame0, uint32_t n_frames,
                           const float4 *L, float4 *out);
 void pt_launch_math(hipStream_t s, int op, uint32_t n, const float *a, const float *b, const float *c, float *out);

@@ -46,7 +46,7 @@ struct ptmi_ctx {
     DevPaths paths{};
     float4 *hits = nullptr;
     DevShadow sh{};
-    uint32_t *queue[2] = {nullptr, nullptr};
+    uint32_t *queue[2] = {nullptr, nullptr}, *sq = nullptr;
     uint64_t *alive = nullptr, *shadowm = nullptr;
     uint32_t *word_off = nullptr, *counts = nullptr;
     unsigned long long *d_stats = nullptr;
@@ -61,6 +61,7 @@ struct ptmi_ctx {
 namespace {
 
 constexpr int kStatsWords = 8 + 64;
+constexpr int kShadowCount = 72;          // slot of the shadow-queue length in ctx->counts (80 words)
 constexpr size_t kLdsMax = 160 * 1024;
 
 int fail(const ptmi_ctx *c, int code, const char *fmt, ...) {
@@ -112,7 +113,7 @@ struct Timed {
 void free_batch(ptmi_ctx *c) {
     dfree(c->paths.O); dfree(c->paths.D); dfree(c->paths.T); dfree(c->paths.L);
     dfree(c->hits); dfree(c->sh.SO); dfree(c->sh.SD); dfree(c->sh.SC);
-    dfree(c->queue[0]); dfree(c->queue[1]); dfree(c->alive); dfree(c->shadowm); dfree(c->word_off); dfree(c->d_occ);
+    dfree(c->queue[0]); dfree(c->queue[1]); dfree(c->sq); dfree(c->alive); dfree(c->shadowm); dfree(c->word_off); dfree(c->d_occ);
     c->cap = 0;
 }
 
@@ -122,14 +123,16 @@ int ensure_capacity(ptmi_ctx *c, size_t n) {
     free_batch(c);
     size_t cap = (n + 1023) & ~(size_t)1023;
     size_t words = cap / 64 + 1;
+    size_t tiles = cap / 65536 + 2;
     HIP_TRY(c, hipMalloc(&c->paths.O, cap * 16)); HIP_TRY(c, hipMalloc(&c->paths.D, cap * 16));
     HIP_TRY(c, hipMalloc(&c->paths.T, cap * 16)); HIP_TRY(c, hipMalloc(&c->paths.L, cap * 16));
     HIP_TRY(c, hipMalloc(&c->hits, cap * 16));
     HIP_TRY(c, hipMalloc(&c->sh.SO, cap * 16)); HIP_TRY(c, hipMalloc(&c->sh.SD, cap * 16));
     HIP_TRY(c, hipMalloc(&c->sh.SC, cap * 16));
     HIP_TRY(c, hipMalloc(&c->queue[0], cap * 4)); HIP_TRY(c, hipMalloc(&c->queue[1], cap * 4));
+    HIP_TRY(c, hipMalloc(&c->sq, cap * 4));
     HIP_TRY(c, hipMalloc(&c->alive, words * 8)); HIP_TRY(c, hipMalloc(&c->shadowm, words * 8));
-    HIP_TRY(c, hipMalloc(&c->word_off, words * 4));
+    HIP_TRY(c, hipMalloc(&c->word_off, 2 * tiles * 4));
     HIP_TRY(c, hipMalloc(&c->d_occ, cap));
     c->cap = cap;
     return PTMI_OK;
@@ -400,6 +403,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     c->st.traversal_used = cfg.variant == PT_VARIANT_LDS ? PTMI_TRAVERSAL_LDS : PTMI_TRAVERSAL_GLOBAL;
     c->st.frames_per_batch_used = F;
     const int blocks = c->n_cu * 8;
+    const int tiles = (int)(c->cap / 65536 + 1);
     const uint32_t maxb = c->opt.max_bounces;
     const bool t1 = c->opt.timing >= 1, t2 = c->opt.timing >= 2;
     {
@@ -413,14 +417,15 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
                 { Timed t(c, 1, t2); pt_launch_extend(c->stream, blocks, cfg, c->sc, c->paths, c->queue[cur], &c->counts[b], c->hits); }
                 { Timed t(c, 2, t2); pt_launch_shade(c->stream, blocks, c->sc, c->paths, c->queue[cur], &c->counts[b], c->hits, c->sh,
                                                      c->alive, c->shadowm, ShadeParams{b, maxb, c->opt.do_mis}); }
-                if (c->opt.do_mis && c->sc.n_lights > 0) {
-                    Timed t(c, 3, t2);
-                    pt_launch_shadow(c->stream, blocks, cfg, c->sc, c->paths, c->sh, c->shadowm, &c->counts[b], nullptr);
-                }
+                const bool nee = c->opt.do_mis && c->sc.n_lights > 0;
                 const bool last = b + 1 == maxb;
-                pt_launch_compact(c->stream, (int)(c->cap / 65536 + 1), c->queue[cur], &c->counts[b], c->alive,
-                                  (c->opt.do_mis && c->sc.n_lights > 0) ? c->shadowm : nullptr, c->word_off,
-                                  c->queue[cur ^ 1], &c->counts[b + 1], c->d_stats, b, last ? 0 : 1);
+                pt_launch_compact(c->stream, tiles, c->queue[cur], &c->counts[b], c->alive, nee ? c->shadowm : nullptr,
+                                  c->word_off, c->queue[cur ^ 1], &c->counts[b + 1], c->sq, &c->counts[kShadowCount],
+                                  c->d_stats, b, last ? 0 : 1);
+                if (nee) {
+                    Timed t(c, 3, t2);
+                    pt_launch_shadow(c->stream, blocks, cfg, c->sc, c->paths, c->sh, c->sq, &c->counts[kShadowCount], nullptr);
+                }
                 cur ^= 1;
             }
             pt_launch_accumulate(c->stream, blocks, band, frame0, fb, c->paths.L, c->d_out);

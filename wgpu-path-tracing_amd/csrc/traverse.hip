@@ -6,19 +6,28 @@
 //            (reference: the sceneIntersect calls of pt.wgsl:392/421/463 and the
 //            occlusion predicates of :394/:423/:465)
 //
-// Result contract (DESIGN.md §3): the same (t, triangle, u, v) as the reference's
+// Result contract (DESIGN.md §3.2): the same (t, triangle, u, v) as the reference's
 // traversal — the minimum t over all triangles in leaves whose ancestors all pass
 // the slab test, ties to the lowest triangle index (= first in the reference's
 // left-first DFS) — reached by an ordered two-box-per-step descent with a
 // conservative distance cull. cull = 0 visits exactly the reference's leaf set.
 //
-// Two memory variants share one traversal body:
+// Execution model: PERSISTENT WAVES. A wave owns a contiguous chunk of the ray queue
+// and keeps 64 rays in flight; when enough lanes have finished their ray, the idle
+// lanes fetch the next rays of the chunk (rank by ballot/popcount, no atomics), so a
+// wave is not held hostage by its slowest ray. Per-ray work on Cornell varies 4x
+// around its mean (measured: max-over-64 / mean = 2.0), which is what this removes.
+//
+// Two memory variants share the body:
 //   global : wide nodes / triangle images read through L1/L2, per-lane stack in LDS
 //   lds    : the whole traversal image staged into LDS once per persistent workgroup
 #include "pt_device.h"
 #include "pt_math.h"
 
 namespace {
+
+constexpr int MODE_EXTEND = 0, MODE_SHADOW = 1;
+constexpr int REFILL_AT = 44;          // refill when at most this many of the 64 lanes still hold a ray
 
 struct GlobalMem {
     const float4 *wn, *tp;
@@ -28,6 +37,17 @@ struct GlobalMem {
     }
     PT_DEV void tri(uint32_t i, float4 &a, float4 &b, float4 &c) const {
         const float4 *p = tp + 3u * (size_t)i;
+        a = p[0]; b = p[1]; c = p[2];
+    }
+};
+struct LdsMem {
+    const float4 *wn, *tp;      // LDS
+    PT_DEV void node(uint32_t i, float4 &a, float4 &b, float4 &c, float4 &d) const {
+        const float4 *p = wn + 4u * i;
+        a = p[0]; b = p[1]; c = p[2]; d = p[3];
+    }
+    PT_DEV void tri(uint32_t i, float4 &a, float4 &b, float4 &c) const {
+        const float4 *p = tp + 3u * i;
         a = p[0]; b = p[1]; c = p[2];
     }
 };
@@ -65,272 +85,246 @@ PT_DEV float cull_limit(float t) { return fma1(t, 1.001f, 1e-4f); }
 
 struct Hit { float t, u, v; uint32_t tri; };
 
-// ANYHIT: returns true at the first accepted hit with (tlim < 0 || t < tlim).
-// Closest: fills `best` (t = +inf, tri = NONE when nothing is hit).
-template <bool ANYHIT, bool CULL, int STACK, class Mem>
-PT_DEV bool traverse(const Mem &m, const DevScene &sc, v3 o, v3 d, float tlim, uint32_t *stk, int stride, Hit &best) {
-    best.t = __builtin_inff(); best.u = 0.0f; best.v = 0.0f; best.tri = PT_REF_NONE;
-    uint32_t cur = sc.root_ref;
-    if (cur == PT_REF_NONE) return false;
-    v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    float limit = __builtin_inff();
-    if (ANYHIT && CULL && !(tlim < 0.0f)) limit = cull_limit(tlim);
-    float tm;
-    if (!slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], o, inv, tm))
-        return false;
+PT_DEV float4 pack_hit(const Hit &h) {
+    if (h.tri == PT_REF_NONE) return make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(PT_REF_NONE));
+    return make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
+}
+
+// ---- ray sources / result sinks of the two kernels ---------------------------------
+struct ExtendIO {
+    const float4 *O, *D; const uint32_t *queue; float4 *hits;
+    PT_DEV void fetch(uint32_t slot, v3 &o, v3 &d, float &tlim) const {
+        uint32_t p = queue ? queue[slot] : slot;
+        float4 o4 = O[p], d4 = D[p];
+        o = xyz(o4); d = xyz(d4); tlim = 0.0f;
+    }
+    PT_DEV void finish(uint32_t slot, const Hit &h, bool) const { hits[slot] = pack_hit(h); }
+};
+struct ShadowIO {
+    DevPaths P; DevShadow S; const uint32_t *sq; uint8_t *occluded_out;
+    PT_DEV void fetch(uint32_t &slot, v3 &o, v3 &d, float &tlim) const {
+        uint32_t i = sq ? sq[slot] : slot;
+        slot = i;                                              // the record's own slot is what finish() needs
+        float4 so = S.SO[i], sd = S.SD[i];
+        o = xyz(so); d = xyz(sd);
+        tlim = so.w < 0.0f ? -1.0f : so.w - PT_EPS * 2.0f;    // pt.wgsl:394 / :423, :465
+    }
+    PT_DEV void finish(uint32_t i, const Hit &, bool occluded) const {
+        if (occluded_out) { occluded_out[i] = occluded ? 1 : 0; return; }
+        if (!occluded) {
+            uint32_t p = __float_as_uint(S.SD[i].w);
+            float4 l = P.L[p], c = S.SC[i];
+            P.L[p] = make_float4(l.x + c.x, l.y + c.y, l.z + c.z, 0.0f);   // pt.wgsl:675
+        }
+    }
+};
+
+// One wave traces the 64-slot groups gw, gw + total_waves, gw + 2 total_waves, ... of a queue of
+// `count` slots (the same interleaving a grid-stride loop gives, so every wave sees a uniform
+// sample of the queue and the waves finish together). Virtual index v of the wave maps to slot
+// ((v >> 6) * total_waves + gw) * 64 + (v & 63). stk: this lane's LDS stack, entries `stride` apart.
+template <int MODE, bool CULL, int STACK, class Mem, class IO>
+PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t count, uint32_t gw,
+                       uint32_t total_waves, uint32_t *stk, int stride) {
+    constexpr bool ANY = MODE == MODE_SHADOW;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t ngroups = (count + 63u) >> 6;
+    const uint32_t end = gw < ngroups ? ((ngroups - gw + total_waves - 1u) / total_waves) * 64u : 0u;   // virtual slots
+    uint32_t next = 0u;                     // wave-uniform virtual index
+    bool active = false;
+    uint32_t slot = 0, cur = 0, tri_i = 0, tri_e = 0;
     int sp = 0;
+    v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), inv = mk3(0, 0, 0);
+    float tlim = 0.0f, limit = __builtin_inff();
+    Hit best; best.t = __builtin_inff(); best.u = best.v = 0.0f; best.tri = PT_REF_NONE;
+
+    // enter a child reference: an internal node becomes `cur`, a leaf becomes the pending range [tri_i, tri_e)
+    auto enter = [&](uint32_t ref) {
+        if (ref & PT_REF_LEAF) {
+            tri_i = ref & PT_LEAF_OFF_MASK;
+            tri_e = tri_i + ((ref >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) + 1u;
+        } else {
+            cur = ref; tri_i = tri_e = 0u;
+        }
+    };
+
     for (;;) {
-        if (!(cur & PT_REF_LEAF)) {
+        uint64_t act = __ballot(active);
+        if (next < end && __popcll(act) <= REFILL_AT) {
+            // idle lanes take the wave's next rays: lane's rank among the idle lanes -> virtual index
+            const uint64_t idle = ~act;
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            const uint32_t vi = next + rank;
+            const uint32_t vslot = ((vi >> 6) * total_waves + gw) * 64u + (vi & 63u);
+            if (!active && vi < end && vslot < count) {
+                slot = vslot;
+                io.fetch(slot, o, d, tlim);
+                inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                best.t = __builtin_inff(); best.u = best.v = 0.0f; best.tri = PT_REF_NONE;
+                sp = 0;
+                limit = (ANY && CULL && !(tlim < 0.0f)) ? cull_limit(tlim) : __builtin_inff();
+                float tm;
+                if (sc.root_ref != PT_REF_NONE &&
+                    slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2],
+                         o, inv, tm)) {
+                    active = true;
+                    enter(sc.root_ref);
+                } else {
+                    io.finish(slot, best, false);              // misses the root box: nothing is tested (pt.wgsl:266)
+                }
+            }
+            next += (uint32_t)__popcll(idle);
+            act = __ballot(active);
+        }
+        if (act == 0ull && next >= end) break;
+
+        // Majority scheduling: a wave runs ONE of the two instruction streams per iteration — the
+        // box step or the triangle test — whichever more of its lanes are waiting for; the others
+        // keep their state. (Running both every iteration costs their sum while each lane uses one.)
+        const bool at_leaf = tri_i < tri_e;                       // idle lanes keep tri_i == tri_e == 0
+        const uint64_t bl = __ballot(active && at_leaf);
+        const bool run_tri = 2 * __popcll(bl) > __popcll(act);    // wave-uniform
+        bool want_pop = false, have_next = false, occluded = false;
+        uint32_t next_ref = 0u;
+        if (run_tri) {
+            if (active && at_leaf) {
+                // the pending leaf's triangles (pt.wgsl:272-279)
+                for (uint32_t ti = tri_i; ti < tri_e; ti++) {
+                    float4 a, b, c;
+                    m.tri(ti, a, b, c);
+                    float u = 0.0f, v = 0.0f;
+                    const float t = tri_test(xyz(a), xyz(b), xyz(c), o, d, u, v);
+                    const bool hit = t > 0.0f;
+                    if (ANY) {
+                        occluded = occluded || (hit && (tlim < 0.0f || t < tlim));
+                    } else {
+                        // pt.wgsl:275 keeps the first strictly nearer hit of a left-first DFS:
+                        // the lowest triangle index among equal t
+                        const bool better = hit && (t < best.t || (t == best.t && ti < best.tri));
+                        best.t = better ? t : best.t; best.u = better ? u : best.u;
+                        best.v = better ? v : best.v; best.tri = better ? ti : best.tri;
+                        if (CULL) limit = better ? cull_limit(t) : limit;
+                    }
+                }
+                tri_i = tri_e;
+                want_pop = !occluded;
+            }
+        } else if (active && !at_leaf) {
             float4 a, b, c, r;
             m.node(cur, a, b, c, r);
             float tl, tr;
             bool hl = slab(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, tl);
             bool hr = slab(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, tr);
             if (CULL) { hl = hl && !(tl > limit); hr = hr && !(tr > limit); }
-            uint32_t lref = __float_as_uint(r.x), rref = __float_as_uint(r.y);
-            if (hl && hr) {
-                bool left_first = tl <= tr;
-                uint32_t far = left_first ? rref : lref;
-                cur = left_first ? lref : rref;
-                if (sp < STACK) { stk[sp * stride] = far; sp++; }
-                continue;
-            }
-            if (hl) { cur = lref; continue; }
-            if (hr) { cur = rref; continue; }
-        } else {
-            uint32_t off = cur & PT_LEAF_OFF_MASK;
-            uint32_t cnt = ((cur >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) + 1u;
-            for (uint32_t k = 0; k < cnt; k++) {
-                uint32_t ti = off + k;
-                float4 a, b, c;
-                m.tri(ti, a, b, c);
-                float u = 0.0f, v = 0.0f;
-                float t = tri_test(xyz(a), xyz(b), xyz(c), o, d, u, v);
-                if (t > 0.0f) {
-                    if (ANYHIT) {
-                        if (tlim < 0.0f || t < tlim) return true;
-                    } else if (t < best.t || (t == best.t && ti < best.tri)) {
-                        // pt.wgsl:275 keeps the first strictly nearer hit of a left-first DFS:
-                        // the lowest triangle index among equal t
-                        best.t = t; best.u = u; best.v = v; best.tri = ti;
-                        if (CULL) limit = cull_limit(t);
-                    }
-                }
-            }
+            const uint32_t lref = __float_as_uint(r.x), rref = __float_as_uint(r.y);
+            const bool left_first = tl <= tr;
+            if (hl && hr && sp < STACK) { stk[sp * stride] = left_first ? rref : lref; sp++; }
+            have_next = hl || hr;
+            next_ref = (hl && (left_first || !hr)) ? lref : rref;
+            want_pop = !have_next;
         }
-        if (sp == 0) break;
-        sp--;
-        cur = stk[sp * stride];
+        bool done = occluded;
+        if (want_pop) {
+            if (sp == 0) done = true;
+            else { sp--; next_ref = stk[sp * stride]; have_next = true; }
+        }
+        if (have_next) {
+            // enter a child reference: an internal node becomes `cur`, a leaf the pending range [tri_i, tri_e)
+            const bool leaf = (next_ref & PT_REF_LEAF) != 0u;
+            const uint32_t off = next_ref & PT_LEAF_OFF_MASK;
+            tri_i = leaf ? off : 0u;
+            tri_e = leaf ? off + ((next_ref >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) + 1u : 0u;
+            cur = leaf ? cur : next_ref;
+        }
+        if (done) { io.finish(slot, best, occluded); active = false; tri_i = tri_e = 0u; }
     }
-    return false;
-}
-
-PT_DEV float4 pack_hit(const Hit &h) {
-    if (h.tri == PT_REF_NONE) return make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(PT_REF_NONE));
-    return make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
 }
 
 // ------------------------------------------------------------------ global ----
 constexpr int GBLOCK = 256;
 
-template <int STACK, bool CULL>
-__global__ __launch_bounds__(GBLOCK) void k_extend_global(DevScene sc, const float4 *__restrict__ O,
-                                                          const float4 *__restrict__ D,
-                                                          const uint32_t *__restrict__ queue,
-                                                          const uint32_t *__restrict__ count_ptr,
-                                                          float4 *__restrict__ hits) {
+template <int MODE, bool CULL, int STACK, class IO>
+__global__ __launch_bounds__(GBLOCK) void k_trace_global(DevScene sc, IO io, const uint32_t *__restrict__ count_ptr) {
     __shared__ uint32_t stk[STACK * GBLOCK];
     const uint32_t count = *count_ptr;
+    const uint32_t gw = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;       // consecutive groups -> different workgroups
+    if (gw * 64u >= count) return;
     GlobalMem m{sc.wnodes, sc.tripos};
-    for (uint32_t i = blockIdx.x * GBLOCK + threadIdx.x; i < count; i += gridDim.x * GBLOCK) {
-        uint32_t p = queue ? queue[i] : i;
-        float4 o4 = O[p], d4 = D[p];
-        Hit h;
-        traverse<false, CULL, STACK>(m, sc, xyz(o4), xyz(d4), -1.0f, stk + threadIdx.x, GBLOCK, h);
-        hits[i] = pack_hit(h);
-    }
-}
-
-template <int STACK, bool CULL>
-__global__ __launch_bounds__(GBLOCK) void k_shadow_global(DevScene sc, DevPaths P, DevShadow S,
-                                                          const uint64_t *__restrict__ mask,
-                                                          const uint32_t *__restrict__ count_ptr,
-                                                          uint8_t *__restrict__ occluded_out) {
-    __shared__ uint32_t stk[STACK * GBLOCK];
-    const uint32_t count = *count_ptr;
-    GlobalMem m{sc.wnodes, sc.tripos};
-    for (uint32_t i = blockIdx.x * GBLOCK + threadIdx.x; i < count; i += gridDim.x * GBLOCK) {
-        if (mask && !((mask[i >> 6] >> (i & 63u)) & 1ull)) continue;
-        float4 so = S.SO[i], sd = S.SD[i];
-        float dist = so.w;
-        float tlim = dist < 0.0f ? -1.0f : dist - PT_EPS * 2.0f;          // pt.wgsl:423, :465
-        Hit h;
-        bool occ = traverse<true, CULL, STACK>(m, sc, xyz(so), xyz(sd), tlim, stk + threadIdx.x, GBLOCK, h);
-        if (occluded_out) { occluded_out[i] = occ ? 1 : 0; continue; }
-        if (!occ) {
-            uint32_t p = __float_as_uint(sd.w);
-            float4 l = P.L[p], c = S.SC[i];
-            P.L[p] = make_float4(l.x + c.x, l.y + c.y, l.z + c.z, 0.0f);  // pt.wgsl:675
-        }
-    }
+    trace_wave<MODE, CULL, STACK>(m, sc, io, count, gw, gridDim.x * (GBLOCK / 64), stk + threadIdx.x, GBLOCK);
 }
 
 // --------------------------------------------------------------------- LDS ----
 // One persistent 1024-thread workgroup per CU stages the traversal image
-// (wide nodes + triangle images) into LDS once, then walks queue chunks.
+// (wide nodes + triangle images) into LDS once, then its 16 waves walk their chunks.
 constexpr int LBLOCK = 1024;
 
-struct LdsMem {
-    const float4 *wn, *tp;      // LDS
-    PT_DEV void node(uint32_t i, float4 &a, float4 &b, float4 &c, float4 &d) const {
-        const float4 *p = wn + 4u * i;
-        a = p[0]; b = p[1]; c = p[2]; d = p[3];
-    }
-    PT_DEV void tri(uint32_t i, float4 &a, float4 &b, float4 &c) const {
-        const float4 *p = tp + 3u * i;
-        a = p[0]; b = p[1]; c = p[2];
-    }
-};
-
-PT_DEV void stage_scene(const DevScene &sc, float4 *smem) {
+template <int MODE, bool CULL, int STACK, class IO>
+__global__ __launch_bounds__(LBLOCK) void k_trace_lds(DevScene sc, IO io, const uint32_t *__restrict__ count_ptr) {
+    extern __shared__ float4 smem[];
+    const uint32_t count = *count_ptr;
+    if (blockIdx.x * 64u >= count) return;      // wave 0 owns group blockIdx.x; if that is empty the whole group is idle
     const uint32_t nw = 4u * sc.n_wnodes, nt = 3u * sc.n_tris;
     for (uint32_t i = threadIdx.x; i < nw; i += LBLOCK) smem[i] = sc.wnodes[i];
     for (uint32_t i = threadIdx.x; i < nt; i += LBLOCK) smem[nw + i] = sc.tripos[i];
     __syncthreads();
-}
-
-template <int STACK, bool CULL>
-__global__ __launch_bounds__(LBLOCK) void k_extend_lds(DevScene sc, const float4 *__restrict__ O,
-                                                       const float4 *__restrict__ D,
-                                                       const uint32_t *__restrict__ queue,
-                                                       const uint32_t *__restrict__ count_ptr,
-                                                       float4 *__restrict__ hits) {
-    extern __shared__ float4 smem[];
-    const uint32_t count = *count_ptr;
-    if (blockIdx.x * LBLOCK >= count) return;                 // whole workgroup has nothing to do
-    stage_scene(sc, smem);
-    LdsMem m{smem, smem + 4u * sc.n_wnodes};
-    uint32_t *stk = reinterpret_cast<uint32_t *>(smem + 4u * sc.n_wnodes + 3u * sc.n_tris) + threadIdx.x;
-    for (uint32_t i = blockIdx.x * LBLOCK + threadIdx.x; i < count; i += gridDim.x * LBLOCK) {
-        uint32_t p = queue ? queue[i] : i;
-        float4 o4 = O[p], d4 = D[p];
-        Hit h;
-        traverse<false, CULL, STACK>(m, sc, xyz(o4), xyz(d4), -1.0f, stk, LBLOCK, h);
-        hits[i] = pack_hit(h);
-    }
-}
-
-template <int STACK, bool CULL>
-__global__ __launch_bounds__(LBLOCK) void k_shadow_lds(DevScene sc, DevPaths P, DevShadow S,
-                                                       const uint64_t *__restrict__ mask,
-                                                       const uint32_t *__restrict__ count_ptr,
-                                                       uint8_t *__restrict__ occluded_out) {
-    extern __shared__ float4 smem[];
-    const uint32_t count = *count_ptr;
-    if (blockIdx.x * LBLOCK >= count) return;
-    stage_scene(sc, smem);
-    LdsMem m{smem, smem + 4u * sc.n_wnodes};
-    uint32_t *stk = reinterpret_cast<uint32_t *>(smem + 4u * sc.n_wnodes + 3u * sc.n_tris) + threadIdx.x;
-    for (uint32_t i = blockIdx.x * LBLOCK + threadIdx.x; i < count; i += gridDim.x * LBLOCK) {
-        if (mask && !((mask[i >> 6] >> (i & 63u)) & 1ull)) continue;
-        float4 so = S.SO[i], sd = S.SD[i];
-        float dist = so.w;
-        float tlim = dist < 0.0f ? -1.0f : dist - PT_EPS * 2.0f;
-        Hit h;
-        bool occ = traverse<true, CULL, STACK>(m, sc, xyz(so), xyz(sd), tlim, stk, LBLOCK, h);
-        if (occluded_out) { occluded_out[i] = occ ? 1 : 0; continue; }
-        if (!occ) {
-            uint32_t p = __float_as_uint(sd.w);
-            float4 l = P.L[p], c = S.SC[i];
-            P.L[p] = make_float4(l.x + c.x, l.y + c.y, l.z + c.z, 0.0f);
-        }
-    }
+    const uint32_t gw = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;
+    if (gw * 64u >= count) return;
+    LdsMem m{smem, smem + nw};
+    uint32_t *stk = reinterpret_cast<uint32_t *>(smem + nw + nt) + threadIdx.x;
+    trace_wave<MODE, CULL, STACK>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk, LBLOCK);
 }
 
 size_t lds_bytes(const TraverseConfig &cfg) {
     return cfg.lds_scene_bytes + (size_t)cfg.stack_entries * LBLOCK * sizeof(uint32_t);
 }
 
-template <int STACK, bool CULL>
-void extend_dispatch(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, DevPaths p,
-                     const uint32_t *queue, const uint32_t *count, float4 *hits) {
+template <int MODE, bool CULL, class IO>
+void launch(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, const IO &io,
+            const uint32_t *count) {
     if (cfg.variant == PT_VARIANT_LDS) {
-        int lb = blocks / 8; if (lb < 1) lb = 1;          // one persistent 1024-thread workgroup per CU
-        hipLaunchKernelGGL((k_extend_lds<STACK, CULL>), dim3(lb), dim3(LBLOCK), lds_bytes(cfg), s, sc, p.O, p.D,
-                           queue, count, hits);
+        int lb = blocks / 8; if (lb < 1) lb = 1;               // one 1024-thread workgroup per CU
+        if (cfg.stack_entries <= 16)
+            hipLaunchKernelGGL((k_trace_lds<MODE, CULL, 16, IO>), dim3(lb), dim3(LBLOCK), lds_bytes(cfg), s, sc, io, count);
+        else
+            hipLaunchKernelGGL((k_trace_lds<MODE, CULL, 32, IO>), dim3(lb), dim3(LBLOCK), lds_bytes(cfg), s, sc, io, count);
+    } else if (cfg.stack_entries <= 16) {
+        hipLaunchKernelGGL((k_trace_global<MODE, CULL, 16, IO>), dim3(blocks), dim3(GBLOCK), 0, s, sc, io, count);
+    } else if (cfg.stack_entries <= 32) {
+        hipLaunchKernelGGL((k_trace_global<MODE, CULL, 32, IO>), dim3(blocks), dim3(GBLOCK), 0, s, sc, io, count);
     } else {
-        hipLaunchKernelGGL((k_extend_global<STACK, CULL>), dim3(blocks), dim3(GBLOCK), 0, s, sc, p.O, p.D, queue,
-                           count, hits);
-    }
-}
-template <int STACK, bool CULL>
-void shadow_dispatch(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, DevPaths p,
-                     DevShadow sh, const uint64_t *mask, const uint32_t *count, uint8_t *occ) {
-    if (cfg.variant == PT_VARIANT_LDS) {
-        int lb = blocks / 8; if (lb < 1) lb = 1;          // one persistent 1024-thread workgroup per CU
-        hipLaunchKernelGGL((k_shadow_lds<STACK, CULL>), dim3(lb), dim3(LBLOCK), lds_bytes(cfg), s, sc, p, sh, mask,
-                           count, occ);
-    } else {
-        hipLaunchKernelGGL((k_shadow_global<STACK, CULL>), dim3(blocks), dim3(GBLOCK), 0, s, sc, p, sh, mask, count,
-                           occ);
+        hipLaunchKernelGGL((k_trace_global<MODE, CULL, 64, IO>), dim3(blocks), dim3(GBLOCK), 0, s, sc, io, count);
     }
 }
 
-template <class F16, class F32, class F64>
-void by_stack(int entries, F16 f16, F32 f32, F64 f64) {
-    if (entries <= 16) f16(); else if (entries <= 32) f32(); else f64();
+template <int MODE, bool CULL, int STACK, class IO>
+hipError_t set_lds(size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_lds<MODE, CULL, STACK, IO>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 }  // namespace
 
 int pt_extend_set_lds_limit(size_t bytes) {
-    hipError_t e = hipSuccess;
-#define PT_SET(K) do { hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void *>(&K), \
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (r != hipSuccess) e = r; } while (0)
-    PT_SET((k_extend_lds<16, true>)); PT_SET((k_extend_lds<16, false>));
-    PT_SET((k_extend_lds<32, true>)); PT_SET((k_extend_lds<32, false>));
-    PT_SET((k_shadow_lds<16, true>)); PT_SET((k_shadow_lds<16, false>));
-    PT_SET((k_shadow_lds<32, true>)); PT_SET((k_shadow_lds<32, false>));
-#undef PT_SET
-    return e == hipSuccess ? 0 : -1;
+    hipError_t e[] = {
+        set_lds<MODE_EXTEND, true, 16, ExtendIO>(bytes), set_lds<MODE_EXTEND, false, 16, ExtendIO>(bytes),
+        set_lds<MODE_EXTEND, true, 32, ExtendIO>(bytes), set_lds<MODE_EXTEND, false, 32, ExtendIO>(bytes),
+        set_lds<MODE_SHADOW, true, 16, ShadowIO>(bytes), set_lds<MODE_SHADOW, false, 16, ShadowIO>(bytes),
+        set_lds<MODE_SHADOW, true, 32, ShadowIO>(bytes), set_lds<MODE_SHADOW, false, 32, ShadowIO>(bytes),
+    };
+    for (hipError_t r : e) if (r != hipSuccess) return -1;
+    return 0;
 }
 
 void pt_launch_extend(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, DevPaths p,
                       const uint32_t *queue, const uint32_t *count, float4 *hits) {
-    const bool lds = cfg.variant == PT_VARIANT_LDS;
-    if (cfg.cull) {
-        by_stack(cfg.stack_entries,
-                 [&] { extend_dispatch<16, true>(s, blocks, cfg, sc, p, queue, count, hits); },
-                 [&] { extend_dispatch<32, true>(s, blocks, cfg, sc, p, queue, count, hits); },
-                 [&] { if (lds) extend_dispatch<32, true>(s, blocks, cfg, sc, p, queue, count, hits);
-                       else hipLaunchKernelGGL((k_extend_global<64, true>), dim3(blocks), dim3(GBLOCK), 0, s, sc, p.O,
-                                               p.D, queue, count, hits); });
-    } else {
-        by_stack(cfg.stack_entries,
-                 [&] { extend_dispatch<16, false>(s, blocks, cfg, sc, p, queue, count, hits); },
-                 [&] { extend_dispatch<32, false>(s, blocks, cfg, sc, p, queue, count, hits); },
-                 [&] { if (lds) extend_dispatch<32, false>(s, blocks, cfg, sc, p, queue, count, hits);
-                       else hipLaunchKernelGGL((k_extend_global<64, false>), dim3(blocks), dim3(GBLOCK), 0, s, sc, p.O,
-                                               p.D, queue, count, hits); });
-    }
+    ExtendIO io{p.O, p.D, queue, hits};
+    if (cfg.cull) launch<MODE_EXTEND, true>(s, blocks, cfg, sc, io, count);
+    else launch<MODE_EXTEND, false>(s, blocks, cfg, sc, io, count);
 }
 
 void pt_launch_shadow(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, DevPaths p,
-                      DevShadow sh, const uint64_t *mask, const uint32_t *count, uint8_t *occ) {
-    const bool lds = cfg.variant == PT_VARIANT_LDS;
-    if (cfg.cull) {
-        by_stack(cfg.stack_entries,
-                 [&] { shadow_dispatch<16, true>(s, blocks, cfg, sc, p, sh, mask, count, occ); },
-                 [&] { shadow_dispatch<32, true>(s, blocks, cfg, sc, p, sh, mask, count, occ); },
-                 [&] { if (lds) shadow_dispatch<32, true>(s, blocks, cfg, sc, p, sh, mask, count, occ);
-                       else hipLaunchKernelGGL((k_shadow_global<64, true>), dim3(blocks), dim3(GBLOCK), 0, s, sc, p, sh,
-                                               mask, count, occ); });
-    } else {
-        by_stack(cfg.stack_entries,
-                 [&] { shadow_dispatch<16, false>(s, blocks, cfg, sc, p, sh, mask, count, occ); },
-                 [&] { shadow_dispatch<32, false>(s, blocks, cfg, sc, p, sh, mask, count, occ); },
-                 [&] { if (lds) shadow_dispatch<32, false>(s, blocks, cfg, sc, p, sh, mask, count, occ);
-                       else hipLaunchKernelGGL((k_shadow_global<64, false>), dim3(blocks), dim3(GBLOCK), 0, s, sc, p, sh,
-                                               mask, count, occ); });
-    }
+                      DevShadow sh, const uint32_t *shadow_queue, const uint32_t *count, uint8_t *occ) {
+    ShadowIO io{p, sh, shadow_queue, occ};
+    if (cfg.cull) launch<MODE_SHADOW, true>(s, blocks, cfg, sc, io, count);
+    else launch<MODE_SHADOW, false>(s, blocks, cfg, sc, io, count);
 }
