@@ -4,8 +4,9 @@
     python bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json configs[1]): synthetic Cornell box, 1920x1080, 8 bounces, MIS on.
-One step = one ptmi_dispatch of --frames-per-step frames (default 8) over the rank's rows;
-the default K = 8 steps therefore render exactly the 64 spp of configs[1]. Scene and output
+One step = one ptmi_dispatch of --frames-per-step frames (default 32, traced as one wavefront
+batch of 66 M paths) over the rank's rows; the default K = 2 steps therefore render exactly the
+64 spp of configs[1]. Scene and output
 live in HBM before the timed region starts (the C ABI copies host blobs at upload).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling over pixel rows —
@@ -69,9 +70,9 @@ def cpu_baseline(scene, width, height, bounces, mis, threads, target_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames-per-step", type=int, default=8)
+    ap.add_argument("--frames-per-step", type=int, default=32)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080, help="rows per GPU")
     ap.add_argument("--bounces", type=int, default=8)
@@ -80,7 +81,7 @@ def main():
     ap.add_argument("--frames-per-batch", type=int, default=0)
     ap.add_argument("--traversal", default="auto", choices=["auto", "global", "lds"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--timing", type=int, default=2, help="library HIP-event timing level (2 = per kernel)")
+    ap.add_argument("--timing", type=int, default=2, help="library HIP-event timing level (2 = every extend launch, 3 = every kernel)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

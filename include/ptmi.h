@@ -53,8 +53,9 @@ typedef struct ptmi_options {
     uint32_t traversal;         /* PTMI_TRAVERSAL_*; AUTO picks LDS when the scene fits */
     uint32_t cull;              /* 1 (default): ordered traversal with conservative distance cull;
                                    0: every box-overlapping leaf is tested, as pt.wgsl:248-291 does */
-    uint32_t timing;            /* 0: none; 1: HIP events around each dispatch (gpu_ms);
-                                   2: also around every extend/shade/shadow launch */
+    uint32_t timing;            /* 0: none; 1: HIP events around each dispatch (gpu_ms); 2: also around every
+                                   extend launch (extend_ms); 3: also around every shade and shadow launch.
+                                   Each event pair costs a few microseconds of stream time. */
     uint32_t reserved[8];
 } ptmi_options;
 

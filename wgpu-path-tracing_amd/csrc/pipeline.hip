@@ -72,16 +72,17 @@ __global__ __launch_bounds__(BLOCK) void k_raygen_list(ptmi_camera cam, uint32_t
 }
 
 // ---- ordered compaction ------------------------------------------------------
-// `shade` leaves one ballot word per 64 queue slots. A tile = 1024 words = 65536 slots,
-// one 1024-thread workgroup.
+// `shade` leaves one ballot word per 64 queue slots. A tile = 256 words = 16384 slots,
+// one 256-thread workgroup.
 //   k_tile_sums : per-tile popcount totals (+ the statistics counters)
 //   k_scatter   : every tile sums the totals of the tiles before it (a few hundred at most),
-//                 scans its own 1024 popcounts (wave shuffles + 16 wave totals in LDS), then each
+//                 scans its own 256 popcounts (wave shuffles + 4 wave totals in LDS), then each
 //                 wave walks its 64 words: word j's mask and base offset are read from lane j,
 //                 lane L keeps slot 64*w+L iff bit L is set, at base + popcount(bits below L).
 // The next queue is therefore the surviving path ids in unchanged (ascending) order, and its
 // length lands in next_count — no host round trip.
-constexpr int TILE_WORDS = 1024;
+constexpr int TILE_WORDS = 256;          // 4 waves per tile: many small tiles spread over all CUs
+constexpr int TILE_WAVES = TILE_WORDS / 64;
 
 __global__ __launch_bounds__(TILE_WORDS) void k_tile_sums(const uint32_t *__restrict__ count_ptr,
                                                           const uint64_t *__restrict__ alive,
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(TILE_WORDS) void k_tile_sums(const uint32_t *__rest
                                                           uint32_t *__restrict__ tile_sums,
                                                           uint32_t *__restrict__ shadow_tile_sums,
                                                           unsigned long long *__restrict__ stats, uint32_t bounce) {
-    __shared__ uint32_t wsum[16], wssum[16];
+    __shared__ uint32_t wsum[TILE_WAVES], wssum[TILE_WAVES];
     const uint32_t count = *count_ptr;
     const uint32_t nwords = (count + 63u) >> 6;
     if (blockIdx.x == 0 && threadIdx.x == 0) { stats[0] += count; stats[8 + bounce] += count; }
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(TILE_WORDS) void k_tile_sums(const uint32_t *__rest
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t t = 0, ts = 0;
-        for (int i = 0; i < 16; i++) { t += wsum[i]; ts += wssum[i]; }
+        for (int i = 0; i < TILE_WAVES; i++) { t += wsum[i]; ts += wssum[i]; }
         tile_sums[blockIdx.x] = t;
         shadow_tile_sums[blockIdx.x] = ts;
         if (ts) atomicAdd(&stats[1], (unsigned long long)ts);          // shadow rays (integer: order-free)
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(TILE_WORDS) void k_scatter(const uint32_t *__restri
                                                         const uint32_t *__restrict__ tile_sums,
                                                         uint32_t *__restrict__ next_queue,
                                                         uint32_t *__restrict__ next_count) {
-    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t wtot[TILE_WAVES];
     __shared__ uint32_t tile_base;
     const uint32_t count = *count_ptr;
     const uint32_t nwords = (count + 63u) >> 6;
@@ -131,11 +132,11 @@ __global__ __launch_bounds__(TILE_WORDS) void k_scatter(const uint32_t *__restri
     for (int off = 32; off > 0; off >>= 1) pre += __shfl_down(pre, off);
     if (lane == 0) wtot[wave] = pre;
     __syncthreads();
-    if (threadIdx.x == 0) { uint32_t t = 0; for (int i = 0; i < 16; i++) t += wtot[i]; tile_base = t; }
+    if (threadIdx.x == 0) { uint32_t t = 0; for (int i = 0; i < TILE_WAVES; i++) t += wtot[i]; tile_base = t; }
     __syncthreads();
     const uint32_t base0 = tile_base;
     __syncthreads();
-    // exclusive scan of this tile's 1024 popcounts
+    // exclusive scan of this tile's popcounts
     const uint32_t w = blockIdx.x * TILE_WORDS + threadIdx.x;
     const uint64_t m = w < nwords ? alive[w] : 0ull;
     const uint32_t c = (uint32_t)__popcll(m);
@@ -236,3 +237,5 @@ void pt_launch_accumulate(hipStream_t s, int blocks, DevBand band, uint32_t fram
 void pt_launch_math(hipStream_t s, int op, uint32_t n, const float *a, const float *b, const float *c, float *out) {
     hipLaunchKernelGGL(k_math, dim3((n + 255) / 256), dim3(256), 0, s, op, n, a, b, c, out);
 }
+
+uint32_t pt_compact_tile_slots(void) { return TILE_WORDS * 64u; }

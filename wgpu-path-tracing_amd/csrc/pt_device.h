@@ -71,7 +71,8 @@ void pt_launch_shade(hipStream_t s, int blocks, const DevScene &sc, DevPaths p, 
                      const uint32_t *count, const float4 *hits, DevShadow sh, uint64_t *alive_mask,
                      uint64_t *shadow_mask, ShadeParams sp);
 // ordered stream compaction of the survivors: masks -> next queue + its count, plus statistics
-// (tiles = ceil(capacity / 65536): one 1024-thread workgroup per 1024 ballot words)
+// (tiles = ceil(capacity / pt_compact_tile_slots()) + 1: one workgroup per tile of ballot words)
+uint32_t pt_compact_tile_slots(void);
 void pt_launch_compact(hipStream_t s, int tiles, const uint32_t *queue, const uint32_t *count,
                        const uint64_t *alive_mask, const uint64_t *shadow_mask, uint32_t *tile_sums,
                        uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_queue, uint32_t *shadow_count,

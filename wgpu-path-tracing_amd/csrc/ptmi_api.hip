@@ -123,7 +123,7 @@ int ensure_capacity(ptmi_ctx *c, size_t n) {
     free_batch(c);
     size_t cap = (n + 1023) & ~(size_t)1023;
     size_t words = cap / 64 + 1;
-    size_t tiles = cap / 65536 + 2;
+    size_t tiles = cap / pt_compact_tile_slots() + 2;
     HIP_TRY(c, hipMalloc(&c->paths.O, cap * 16)); HIP_TRY(c, hipMalloc(&c->paths.D, cap * 16));
     HIP_TRY(c, hipMalloc(&c->paths.T, cap * 16)); HIP_TRY(c, hipMalloc(&c->paths.L, cap * 16));
     HIP_TRY(c, hipMalloc(&c->hits, cap * 16));
@@ -392,7 +392,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     if (band.y0 >= band.y1) return fail(c, PTMI_E_INVALID, "tile rows [%u,%u) outside the %u-row frame", band.y0, band.y1, c->H);
     const uint64_t npix = (uint64_t)(band.y1 - band.y0) * band.width;
     uint32_t F = c->opt.frames_per_batch;
-    if (F == 0) { F = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, (8ull << 20) / npix)); }
+    if (F == 0) { F = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, (64ull << 20) / npix)); }   // ~64 Mi paths, ~10 GB of state
     F = std::min(F, n_frames);
     if (npix * F > 0xFFFFFF00ull) return fail(c, PTMI_E_UNSUPPORTED, "batch of %llu paths exceeds 2^32", (unsigned long long)(npix * F));
     rc = ensure_capacity(c, (size_t)(npix * F));
@@ -403,9 +403,9 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     c->st.traversal_used = cfg.variant == PT_VARIANT_LDS ? PTMI_TRAVERSAL_LDS : PTMI_TRAVERSAL_GLOBAL;
     c->st.frames_per_batch_used = F;
     const int blocks = c->n_cu * 8;
-    const int tiles = (int)(c->cap / 65536 + 1);
+    const int tiles = (int)(c->cap / pt_compact_tile_slots() + 1);
     const uint32_t maxb = c->opt.max_bounces;
-    const bool t1 = c->opt.timing >= 1, t2 = c->opt.timing >= 2;
+    const bool t1 = c->opt.timing >= 1, t2 = c->opt.timing >= 2, t3 = c->opt.timing >= 3;
     {
         Timed td(c, 0, t1);
         for (uint32_t f0 = 0; f0 < n_frames; f0 += F) {
@@ -415,7 +415,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
             int cur = 0;
             for (uint32_t b = 0; b < maxb; b++) {
                 { Timed t(c, 1, t2); pt_launch_extend(c->stream, blocks, cfg, c->sc, c->paths, c->queue[cur], &c->counts[b], c->hits); }
-                { Timed t(c, 2, t2); pt_launch_shade(c->stream, blocks, c->sc, c->paths, c->queue[cur], &c->counts[b], c->hits, c->sh,
+                { Timed t(c, 2, t3); pt_launch_shade(c->stream, blocks, c->sc, c->paths, c->queue[cur], &c->counts[b], c->hits, c->sh,
                                                      c->alive, c->shadowm, ShadeParams{b, maxb, c->opt.do_mis}); }
                 const bool nee = c->opt.do_mis && c->sc.n_lights > 0;
                 const bool last = b + 1 == maxb;
@@ -423,7 +423,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
                                   c->word_off, c->queue[cur ^ 1], &c->counts[b + 1], c->sq, &c->counts[kShadowCount],
                                   c->d_stats, b, last ? 0 : 1);
                 if (nee) {
-                    Timed t(c, 3, t2);
+                    Timed t(c, 3, t3);
                     pt_launch_shadow(c->stream, blocks, cfg, c->sc, c->paths, c->sh, c->sq, &c->counts[kShadowCount], nullptr);
                 }
                 cur ^= 1;

@@ -62,21 +62,22 @@ PT_DEV bool slab(float bx0, float by0, float bz0, float bx1, float by1, float bz
     return tmax >= tmin && tmax >= 0.0f;
 }
 
-// pt.wgsl:128-158; returns t (> 1e-6) or -1
+// pt.wgsl:128-158; returns t (> 1e-6) or -1. Straight-line: the reference's four early returns
+// (:134, :143, :151, :157) are folded into one predicate with the same NaN behaviour (a NaN never
+// triggers an early return there, and fails the final t > EPSILON here as there).
 PT_DEV float tri_test(v3 v0, v3 e1, v3 e2, v3 o, v3 d, float &uo, float &vo) {
     v3 h = cross3(d, e2);
     float a = dot3(e1, h);
-    if (__builtin_fabsf(a) < PT_EPS) return -1.0f;
     float f = 1.0f / a;
     v3 sv = sub3(o, v0);
     float u = f * dot3(sv, h);
-    if (u < 0.0f || u > 1.0f) return -1.0f;
     v3 q = cross3(sv, e1);
     float v = f * dot3(d, q);
-    if (v < 0.0f || u + v > 1.0f) return -1.0f;
     float t = f * dot3(e2, q);
-    if (t > PT_EPS) { uo = u; vo = v; return t; }
-    return -1.0f;
+    bool reject = (__builtin_fabsf(a) < PT_EPS) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f);
+    bool ok = !reject & (t > PT_EPS);
+    uo = u; vo = v;
+    return ok ? t : -1.0f;
 }
 
 // distance beyond which a box cannot hold a nearer hit; the slack covers the
