@@ -197,11 +197,11 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                     const float t = tri_test(xyz(a), xyz(b), xyz(c), o, d, u, v);
                     const bool hit = t > 0.0f;
                     if (ANY) {
-                        occluded = occluded || (hit && (tlim < 0.0f || t < tlim));
+                        occluded = occluded | (hit & ((tlim < 0.0f) | (t < tlim)));
                     } else {
                         // pt.wgsl:275 keeps the first strictly nearer hit of a left-first DFS:
                         // the lowest triangle index among equal t
-                        const bool better = hit && (t < best.t || (t == best.t && ti < best.tri));
+                        const bool better = hit & ((t < best.t) | ((t == best.t) & (ti < best.tri)));
                         best.t = better ? t : best.t; best.u = better ? u : best.u;
                         best.v = better ? v : best.v; best.tri = better ? ti : best.tri;
                         if (CULL) limit = better ? cull_limit(t) : limit;
@@ -216,12 +216,12 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
             float tl, tr;
             bool hl = slab(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, tl);
             bool hr = slab(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, tr);
-            if (CULL) { hl = hl && !(tl > limit); hr = hr && !(tr > limit); }
+            if (CULL) { hl = hl & !(tl > limit); hr = hr & !(tr > limit); }
             const uint32_t lref = __float_as_uint(r.x), rref = __float_as_uint(r.y);
             const bool left_first = tl <= tr;
-            if (hl && hr && sp < STACK) { stk[sp * stride] = left_first ? rref : lref; sp++; }
-            have_next = hl || hr;
-            next_ref = (hl && (left_first || !hr)) ? lref : rref;
+            if (hl & hr & (sp < STACK)) { stk[sp * stride] = left_first ? rref : lref; sp++; }
+            have_next = hl | hr;
+            next_ref = (hl & (left_first | !hr)) ? lref : rref;
             want_pop = !have_next;
         }
         bool done = occluded;
