@@ -84,7 +84,7 @@ def _test_rays(scene, n, seed):
     return o, d.astype(np.float32)
 
 
-@pytest.mark.parametrize("name", ["cornell", "feature_box", "cornell_spheres"])
+@pytest.mark.parametrize("name", ["cornell", "feature_box", "cornell_spheres", "grid_1m"])
 @pytest.mark.parametrize("cull", [1, 0])
 @pytest.mark.parametrize("trav", ["global", "lds"])
 def test_extend_parity(gpu_ctx, oracle, scene_factory, name, cull, trav):
@@ -133,7 +133,8 @@ RENDER_CASES = [
     ("cornell", 64, 64, 4, 4, 0, 0.001),          # BASELINE config 1 shape (MIS off, 4 bounces), reduced
     ("cornell_glass", 80, 60, 5, 8, 1, 0.0),
     ("feature_box", 72, 72, 6, 8, 1, 0.05),
-    ("cornell_spheres", 64, 48, 3, 8, 1, 0.001),
+    ("cornell_spheres", 64, 48, 3, 8, 1, 0.001),    # BASELINE configs[2] scene (atlas sampling), reduced
+    ("grid_1m", 96, 54, 2, 8, 1, 0.001),            # BASELINE configs[3] scene: 999 708 triangles, depth-29 BVH
 ]
 
 
