@@ -46,6 +46,23 @@ def pipeline_bytes_per_segment(do_mis, mean_len):
     return seg + (68 + 48) / max(mean_len, 1e-9)
 
 
+def pmc_traffic(default_workload):
+    """HBM bytes per extend launch from the committed rocprofv3 PMC passes of this exact command
+    (profiles/r01_bench_n1_pmc.json: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs, KB per
+    launch; gfx950 tallies wide reads at half: traffic = 2*FETCH_SIZE + WRITE_SIZE). None when the
+    workload differs from the profiled one — counters cannot be read from inside the timed run."""
+    path = os.path.join(ROOT, "profiles", "r01_bench_n1_pmc.json")
+    if not default_workload or not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    try:
+        f = d["FETCH_SIZE"]["k_trace_lds/extend"]["avg_KB_per_launch"]
+        w = d["WRITE_SIZE"]["k_trace_lds/extend"]["avg_KB_per_launch"]
+    except KeyError:
+        return None
+    return int((2 * f + w) * 1024)
+
+
 def cpu_baseline(scene, width, height, bounces, mis, threads, target_s=12.0):
     """Oracle on whole frames of the same camera: 1 calibration frame, then as many frames as
     fit in about target_s seconds (at most the 64 of the workload)."""
@@ -181,7 +198,10 @@ def main():
                 "bound": "hbm", "kernel": "extend (closest-hit BVH traversal)",
                 "achieved": None if ext_gbs is None else round(ext_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": None if ext_gbs is None else round(ext_gbs / HBM_PEAK_GBS, 6),
-                "traffic": None,
+                "traffic": pmc_traffic(args.scene == "cornell" and W == 1920 and args.height == 1080 and fps == 32
+                                       and world == 1 and args.traversal == "auto" and mis and args.bounces == 8),
+                "traffic_note": "bytes per extend launch, 2*FETCH_SIZE+WRITE_SIZE from profiles/r01_bench_n1_pmc.json",
+                "algorithmic_bytes_per_launch": int(st.segments * EXTEND_BYTES_PER_RAY / max(st.extend_launches, 1)),
                 "bytes_per_unit": EXTEND_BYTES_PER_RAY, "units_per_launch": round(st.segments / max(st.extend_launches, 1), 1),
                 "avg_launch_ms": round(ext_ms, 4), "launches": int(st.extend_launches),
                 "pipeline_bytes_per_segment": round(b_seg, 1),
