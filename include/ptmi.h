@@ -119,6 +119,12 @@ int ptmi_bind_output_device(ptmi_ctx *ctx, void *device_ptr, size_t bytes);
 /* Order this context's work on a caller-owned hipStream_t (NULL = the context's own). */
 int ptmi_set_stream(ptmi_ctx *ctx, void *hip_stream);
 
+/* ---- presentation (the reference's blit pass, src/shader/blit.wgsl:43-155; renderer.ts:434-449) ---- */
+/* Tone-maps the output buffer (exposure 2^1, AgX, gamma 1/2.2) into a width*height canvas, row 0 = top.
+ * dst_rgba_f32 (width*height*4 floats, alpha 1) and/or dst_rgba8 (width*height*4 bytes); either may be NULL.
+ * Synchronises. Uses the device's log2/pow: compared with a tolerance, not bit for bit. */
+int ptmi_blit(ptmi_ctx *ctx, float *dst_rgba_f32, uint8_t *dst_rgba8);
+
 /* ---- statistics ----------------------------------------------------------- */
 int ptmi_get_stats(ptmi_ctx *ctx, ptmi_stats *out);           /* synchronises */
 int ptmi_reset_stats(ptmi_ctx *ctx);

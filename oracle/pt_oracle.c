@@ -874,6 +874,38 @@ void pto_ordered_counts(const pto_scene *s, uint32_t n, const float *o3, const f
     }
 }
 
+/* blit.wgsl:43-155 — tone map + gamma of the output buffer into a W x H canvas (row 0 = top). Plain libm
+ * (log2f / powf): this pass is compared with a tolerance, not bit for bit. */
+static float agx_contrast1(float v) {                                          /* blit.wgsl:54-65 */
+    float x2 = v * v, x4 = x2 * x2;
+    return 15.5f * x4 * x2 - 40.14f * x4 * v + 31.96f * x4 - 6.868f * x2 * v + 0.4298f * x2 + 0.1191f * v - 0.00232f;
+}
+void pto_blit(const float *rgba, uint32_t W, uint32_t H, float *out_rgba) {
+    const float min_ev = -12.47393f, max_ev = 4.026069f;
+    for (uint32_t j = 0; j < H; j++)
+        for (uint32_t i = 0; i < W; i++) {
+            float uvx = ((float)i + 0.5f) / (float)W, uvy = ((float)j + 0.5f) / (float)H;
+            uint32_t x = f2u(uvx * (float)(W - 1u)), y = f2u((1.0f - uvy) * (float)(H - 1u));   /* :148-150 */
+            const float *c = rgba + ((size_t)y * W + x) * 4;
+            float cx = c[0] * 2.0f, cy = c[1] * 2.0f, cz = c[2] * 2.0f;                         /* :51, :134 */
+            float r[3] = { 0.842479062253094f * cx + 0.0784335999999992f * cy + 0.0792237451477643f * cz,
+                           0.0423282422610123f * cx + 0.878468636469772f * cy + 0.0791661274605434f * cz,
+                           0.0423756549057051f * cx + 0.0784336f * cy + 0.879142973793104f * cz };
+            for (int k = 0; k < 3; k++) {
+                float l = min1(max1(log2f(r[k]), min_ev), max_ev);                              /* :81 */
+                r[k] = agx_contrast1((l - min_ev) / (max_ev - min_ev));
+            }
+            float luma = r[0] * 0.2126f + r[1] * 0.7152f + r[2] * 0.0722f;                      /* :102-114 */
+            for (int k = 0; k < 3; k++) r[k] = luma + (powf(r[k], 1.0f) - luma);
+            float e[3] = { 1.19687900512017f * r[0] - 0.0980208811401368f * r[1] - 0.0990297440797205f * r[2],
+                           -0.0528968517574562f * r[0] + 1.15190312990417f * r[1] - 0.0989611768448433f * r[2],
+                           -0.0529716355144438f * r[0] - 0.0980434501171241f * r[1] + 1.15107367264116f * r[2] };
+            float *o = out_rgba + ((size_t)j * W + i) * 4;
+            for (int k = 0; k < 3; k++) o[k] = powf(powf(e[k], 2.2f), 1.0f / 2.2f);             /* :99, :46, :153 */
+            o[3] = 1.0f;
+        }
+}
+
 /* arithmetic-contract probe, same op codes as ptmi_debug_math (include/ptmi.h) */
 void pto_math(int op, uint32_t n, const float *a, const float *b, const float *c, float *out) {
     for (uint32_t i = 0; i < n; i++) {

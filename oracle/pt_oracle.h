@@ -100,6 +100,9 @@ int pto_render(const pto_scene *s, const ptmi_camera *cam, uint32_t n_frames,
 int pto_trace_path(const pto_scene *s, const ptmi_camera *cam, uint32_t x, uint32_t y,
                    uint32_t frame, const pto_options *opt, float *radiance3, float *log16);
 
+/* blit.wgsl:43-155 (presentation pass; tolerance-compared). rgba/out: W*H*4 floats, out row 0 = canvas top. */
+void pto_blit(const float *rgba, uint32_t W, uint32_t H, float *out_rgba);
+
 /* out[i] = op(a[i], b[i], c[i]) with the contract's scalar helpers; op codes as
  * ptmi_debug_math in include/ptmi.h */
 void pto_math(int op, uint32_t n, const float *a, const float *b, const float *c, float *out);

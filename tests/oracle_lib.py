@@ -135,6 +135,13 @@ class Oracle:
         assert rc == 0
         return out, st
 
+    def blit(self, rgba):
+        rgba = np.ascontiguousarray(rgba, np.float32)
+        H, W = rgba.shape[:2]
+        out = np.zeros_like(rgba)
+        self.L.pto_blit(_ptr(rgba), W, H, _ptr(out))
+        return out
+
     def trace_path(self, scene, cam, x, y, frame, max_bounces=8, do_mis=1):
         opt = PtoOptions(max_bounces, do_mis, 0, 0, 1)
         rad = np.zeros(3, np.float32)

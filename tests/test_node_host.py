@@ -71,3 +71,21 @@ def test_node_render_matches_oracle(tmp_path, oracle, batch):
     ref, ost = oracle.render(sc, layout.make_camera(W, H), 16, max_bounces=4, do_mis=0)
     assert st["segments"] == ost.segments and st["paths"] == ost.paths
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_node_blit_png(tmp_path, oracle):
+    """JS host -> addon.blit -> PNG: the tone-mapped canvas matches the oracle's blit of the same buffer."""
+    from PIL import Image
+    _build_addon()
+    sc = scenes.make("cornell")
+    scene_io.save_ptscene(sc, str(tmp_path / "cornell.ptscene"))
+    W, H = 128, 72
+    subprocess.check_output([NODE, os.path.join(HOST, "render_cli.js"), str(tmp_path / "cornell.ptscene"),
+                             str(tmp_path / "out.f32"), "--width", str(W), "--height", str(H), "--frames", "8",
+                             "--batch", "8", "--png", str(tmp_path / "out.png")], text=True)
+    hdr = np.fromfile(tmp_path / "out.f32", np.float32).reshape(H, W, 4)
+    png = np.array(Image.open(tmp_path / "out.png"))
+    ref8 = (np.clip(np.nan_to_num(oracle.blit(hdr), nan=0.0), 0, 1) * 255 + 0.5).astype(np.uint8)
+    assert png.shape == (H, W, 4) and (png[..., 3] == 255).all()
+    assert (png[..., :3] == ref8[..., :3]).all(axis=-1).mean() >= 0.999

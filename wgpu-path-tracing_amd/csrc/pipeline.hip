@@ -184,6 +184,58 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(DevBand band, uint32_t fra
     }
 }
 
+// ---- presentation: src/shader/blit.wgsl:43-155 (exposure 2^1, AgX, look, EOTF, gamma 1/2.2) -------------
+// Not on the parity-exact path: log2 / pow are the device's own (accurate) library functions; the
+// test bar is |gpu - oracle| <= 2e-5 per channel and equal 8-bit codes on >= 99.9 % of pixels.
+PT_DEV v3 agx_contrast(v3 x) {                                   // blit.wgsl:54-65
+    auto f = [](float v) {
+        float x2 = v * v, x4 = x2 * x2;
+        return 15.5f * x4 * x2 - 40.14f * x4 * v + 31.96f * x4 - 6.868f * x2 * v + 0.4298f * x2 + 0.1191f * v - 0.00232f;
+    };
+    return mk3(f(x.x), f(x.y), f(x.z));
+}
+PT_DEV v3 tone_map(v3 c) {                                       // blit.wgsl:133-145
+    c = scale3(c, 2.0f);                                         // exposureAdjust: color * exp2(1.0)
+    // agx(): inset matrix (column-major mat3x3f * vec3), log2 encoding, sigmoid approximation (:67-86)
+    v3 r = mk3(0.842479062253094f * c.x + 0.0784335999999992f * c.y + 0.0792237451477643f * c.z,
+               0.0423282422610123f * c.x + 0.878468636469772f * c.y + 0.0791661274605434f * c.z,
+               0.0423756549057051f * c.x + 0.0784336f * c.y + 0.879142973793104f * c.z);
+    const float min_ev = -12.47393f, max_ev = 4.026069f;
+    r = mk3(min1(max1(__builtin_log2f(r.x), min_ev), max_ev), min1(max1(__builtin_log2f(r.y), min_ev), max_ev),
+            min1(max1(__builtin_log2f(r.z), min_ev), max_ev));
+    r = mk3((r.x - min_ev) / (max_ev - min_ev), (r.y - min_ev) / (max_ev - min_ev), (r.z - min_ev) / (max_ev - min_ev));
+    r = agx_contrast(r);
+    // agxLook(): default look, slope = power = sat = 1 (:102-114)
+    float luma = r.x * 0.2126f + r.y * 0.7152f + r.z * 0.0722f;
+    r = mk3(luma + (__builtin_powf(r.x, 1.0f) - luma), luma + (__builtin_powf(r.y, 1.0f) - luma),
+            luma + (__builtin_powf(r.z, 1.0f) - luma));
+    // agxEotf(): outset matrix, then ^2.2 (:88-100)
+    v3 e = mk3(1.19687900512017f * r.x - 0.0980208811401368f * r.y - 0.0990297440797205f * r.z,
+               -0.0528968517574562f * r.x + 1.15190312990417f * r.y - 0.0989611768448433f * r.z,
+               -0.0529716355144438f * r.x - 0.0980434501171241f * r.y + 1.15107367264116f * r.z);
+    return mk3(__builtin_powf(e.x, 2.2f), __builtin_powf(e.y, 2.2f), __builtin_powf(e.z, 2.2f));
+}
+// one thread per canvas pixel (i, j), j from the top; fragmentMain, blit.wgsl:147-155
+__global__ __launch_bounds__(BLOCK) void k_blit(uint32_t W, uint32_t H, const float4 *__restrict__ color,
+                                                float4 *__restrict__ out_f32, uint32_t *__restrict__ out_rgba8) {
+    const uint32_t n = W * H;
+    for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < n; k += gridDim.x * BLOCK) {
+        const uint32_t i = k % W, j = k / W;
+        const float uvx = ((float)i + 0.5f) / (float)W, uvy = ((float)j + 0.5f) / (float)H;
+        const uint32_t x = f2u(uvx * (float)(W - 1u));
+        const uint32_t y = f2u((1.0f - uvy) * (float)(H - 1u));
+        const float4 c4 = color[(size_t)y * W + x];
+        v3 c = tone_map(mk3(c4.x, c4.y, c4.z));
+        const float g = 1.0f / 2.2f;
+        c = mk3(__builtin_powf(c.x, g), __builtin_powf(c.y, g), __builtin_powf(c.z, g));   // gammaCorrect
+        if (out_f32) out_f32[k] = make_float4(c.x, c.y, c.z, 1.0f);
+        if (out_rgba8) {
+            auto q = [](float v) { v = min1(max1(v, 0.0f), 1.0f); return (uint32_t)(v * 255.0f + 0.5f); };   // NaN -> 0
+            out_rgba8[k] = q(c.x) | (q(c.y) << 8) | (q(c.z) << 16) | 0xFF000000u;
+        }
+    }
+}
+
 __global__ void k_math(int op, uint32_t n, const float *a, const float *b, const float *c, float *out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -233,6 +285,10 @@ void pt_launch_compact(hipStream_t s, int tiles, const uint32_t *queue, const ui
 void pt_launch_accumulate(hipStream_t s, int blocks, DevBand band, uint32_t frame0, uint32_t n_frames,
                           const float4 *L, float4 *out) {
     hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(BLOCK), 0, s, band, frame0, n_frames, L, out);
+}
+void pt_launch_blit(hipStream_t s, int blocks, uint32_t W, uint32_t H, const float4 *color, float4 *out_f32,
+                    uint32_t *out_rgba8) {
+    hipLaunchKernelGGL(k_blit, dim3(blocks), dim3(BLOCK), 0, s, W, H, color, out_f32, out_rgba8);
 }
 void pt_launch_math(hipStream_t s, int op, uint32_t n, const float *a, const float *b, const float *c, float *out) {
     hipLaunchKernelGGL(k_math, dim3((n + 255) / 256), dim3(256), 0, s, op, n, a, b, c, out);

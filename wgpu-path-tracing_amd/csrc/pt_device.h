@@ -79,6 +79,8 @@ void pt_launch_compact(hipStream_t s, int tiles, const uint32_t *queue, const ui
                        unsigned long long *stats, uint32_t bounce, int do_scatter);
 void pt_launch_accumulate(hipStream_t s, int blocks, DevBand band, uint32_t frame0, uint32_t n_frames,
                           const float4 *L, float4 *out);
+void pt_launch_blit(hipStream_t s, int blocks, uint32_t W, uint32_t H, const float4 *color, float4 *out_f32,
+                    uint32_t *out_rgba8);
 void pt_launch_math(hipStream_t s, int op, uint32_t n, const float *a, const float *b, const float *c, float *out);
 
 int pt_extend_set_lds_limit(size_t bytes);   // raises the dynamic-LDS cap of the LDS-variant kernels

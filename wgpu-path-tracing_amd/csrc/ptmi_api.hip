@@ -487,6 +487,24 @@ int ptmi_set_stream(ptmi_ctx *c, void *s) {
     return PTMI_OK;
 }
 
+int ptmi_blit(ptmi_ctx *c, float *dst_f32, uint8_t *dst_rgba8) {
+    if (!c) return PTMI_E_INVALID;
+    if (!c->d_out) return fail(c, PTMI_E_STATE, "no output buffer (ptmi_resize)");
+    if (!dst_f32 && !dst_rgba8) return PTMI_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->W * c->H;
+    float4 *df = nullptr; uint32_t *d8 = nullptr;
+    if (dst_f32) HIP_TRY(c, hipMalloc(&df, n * 16));
+    if (dst_rgba8) HIP_TRY(c, hipMalloc(&d8, n * 4));
+    pt_launch_blit(c->stream, c->n_cu * 8, c->W, c->H, c->d_out, df, d8);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    drain_events(c);
+    if (dst_f32) HIP_TRY(c, hipMemcpy(dst_f32, df, n * 16, hipMemcpyDeviceToHost));
+    if (dst_rgba8) HIP_TRY(c, hipMemcpy(dst_rgba8, d8, n * 4, hipMemcpyDeviceToHost));
+    dfree(df); dfree(d8);
+    return PTMI_OK;
+}
+
 int ptmi_get_stats(ptmi_ctx *c, ptmi_stats *out) {
     if (!c || !out) return PTMI_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));

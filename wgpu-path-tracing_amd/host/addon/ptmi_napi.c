@@ -218,6 +218,20 @@ static napi_value js_write_output(napi_env env, napi_callback_info info) {
     return NULL;
 }
 
+/* blit(ctx, Uint8Array dstRgba8) — the reference's blit pass (blit.wgsl) into an 8-bit canvas, row 0 = top */
+static napi_value js_blit(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return NULL;
+    ptmi_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    void *p; size_t n;
+    if (!get_bytes(env, argv[1], &p, &n)) return NULL;
+    if (!p) { napi_throw_type_error(env, NULL, "expected a Uint8Array of width*height*4 bytes"); return NULL; }
+    int rc = ptmi_blit(ctx, NULL, (uint8_t *)p);
+    if (rc) return throw_ptmi(env, ctx, rc, "ptmi_blit");
+    return argv[1];
+}
+
 static void set_num(napi_env env, napi_value obj, const char *k, double v) {
     napi_value n;
     if (napi_create_double(env, v, &n) == napi_ok) napi_set_named_property(env, obj, k, n);
@@ -262,7 +276,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"abiVersion", js_abi_version}, {"create", js_create}, {"destroy", js_destroy},
         {"uploadScene", js_upload_scene}, {"uploadAtlas", js_upload_atlas}, {"resize", js_resize},
         {"setOptions", js_set_options}, {"dispatch", js_dispatch}, {"synchronize", js_synchronize},
-        {"readOutput", js_read_output}, {"writeOutput", js_write_output}, {"getStats", js_get_stats},
+        {"readOutput", js_read_output}, {"writeOutput", js_write_output}, {"blit", js_blit}, {"getStats", js_get_stats},
         {"resetStats", js_reset_stats},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {

@@ -41,6 +41,8 @@ export class Renderer {
   moveCamera(forward: number, right: number, up: number): void;
   rotateCamera(yaw: number, pitch: number): void;
   readOutput(): Float32Array;
+  /** blit pass (blit.wgsl): tone-mapped RGBA8 canvas, row 0 = top */
+  blit(): Uint8Array;
   setOptions(o: TraceOptions): void;
   getStats(): Stats;
 }

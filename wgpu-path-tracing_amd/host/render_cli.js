@@ -4,7 +4,7 @@
  * render_cli.js — drives the Renderer the way the reference's frame loop does
  * (renderer.ts:415-454: one dispatch per frame, frameIndex++), headless:
  *   node render_cli.js <scene.ptscene> <out.f32> [--width W --height H --frames N --bounces B --mis 0|1
- *                       --aperture A --focus F --batch K]
+ *                       --aperture A --focus F --batch K --png out.png]
  * --batch K traces K frames per dispatch instead of one. Writes W*H*4 float32 (the output buffer)
  * and prints one JSON line with the statistics.
  */
@@ -29,6 +29,8 @@ r.loadModel(scenePath).then(function () {
   var out = r.readOutput();
   var ms = Date.now() - t0;
   fs.writeFileSync(outPath, Buffer.from(out.buffer));
+  var pi = process.argv.indexOf('--png');
+  if (pi >= 0) fs.writeFileSync(process.argv[pi + 1], require('./png').encodePNG(r.blit(), W, H));
   var st = r.getStats();
   st.wallMs = ms; st.width = W; st.height = H; st.frames = frames;
   console.log(JSON.stringify(st));

@@ -166,6 +166,13 @@ Renderer.prototype.readOutput = function () {
   return out;
 };
 
+/** The reference's blit pass (renderer.ts:434-449, blit.wgsl): tone-mapped 8-bit canvas, row 0 = top. */
+Renderer.prototype.blit = function () {
+  var out = new Uint8Array(this.width * this.height * 4);
+  this.addon.blit(this.ctx, out);
+  return out;
+};
+
 Renderer.prototype.setOptions = function (o) { this.addon.setOptions(this.ctx, o); };
 Renderer.prototype.getStats = function () { return this.addon.getStats(this.ctx); };
 

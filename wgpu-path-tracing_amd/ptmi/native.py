@@ -20,7 +20,7 @@ EXPORTS = [
     "ptmi_abi_version", "ptmi_create", "ptmi_destroy", "ptmi_last_error", "ptmi_upload_scene",
     "ptmi_upload_atlas", "ptmi_resize", "ptmi_set_options", "ptmi_get_options", "ptmi_dispatch",
     "ptmi_synchronize", "ptmi_read_output", "ptmi_write_output", "ptmi_output_device_ptr",
-    "ptmi_bind_output_device", "ptmi_set_stream", "ptmi_get_stats", "ptmi_reset_stats",
+    "ptmi_bind_output_device", "ptmi_set_stream", "ptmi_blit", "ptmi_get_stats", "ptmi_reset_stats",
     "ptmi_debug_raygen", "ptmi_debug_intersect", "ptmi_debug_occluded", "ptmi_debug_math",
 ]
 
@@ -83,6 +83,7 @@ def load():
         L.ptmi_write_output.argtypes = [vp, vp, sz]
         L.ptmi_bind_output_device.argtypes = [vp, vp, sz]
         L.ptmi_set_stream.argtypes = [vp, vp]
+        L.ptmi_blit.argtypes = [vp, vp, vp]
         L.ptmi_get_stats.argtypes = [vp, vp]
         L.ptmi_reset_stats.argtypes = [vp]
         L.ptmi_debug_raygen.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp]
@@ -184,6 +185,13 @@ class Context:
 
     def set_stream(self, stream_handle):
         self._ck(self.L.ptmi_set_stream(self.h, ctypes.c_void_p(stream_handle)))
+
+    def blit(self, want_f32=True, want_rgba8=True):
+        """The reference's blit pass (blit.wgsl): (canvas float RGBA or None, canvas uint8 RGBA or None), row 0 = top."""
+        f = np.empty((self.height, self.width, 4), np.float32) if want_f32 else None
+        b = np.empty((self.height, self.width, 4), np.uint8) if want_rgba8 else None
+        self._ck(self.L.ptmi_blit(self.h, _p(f), _p(b)))
+        return f, b
 
     def stats(self):
         s = Stats()
