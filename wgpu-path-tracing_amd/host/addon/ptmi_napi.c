@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include "ptmi.h"
+#include "ptmi_scene.h"
 
 #define NAPI_OK(env, call)                                                        \
     do {                                                                          \
@@ -264,6 +265,63 @@ static napi_value js_reset_stats(napi_env env, napi_callback_info info) {
     return NULL;
 }
 
+/* ---- host-side scene preparation (include/ptmi_scene.h, libptmi_scene.so; no GPU involved) ---- */
+
+/* buildBvh(trianglesArrayBuffer) -> { nodes: ArrayBuffer (48-B nodes), depth }; sorts the triangles in place
+ * exactly like src/renderer/bvh.ts does */
+static napi_value js_build_bvh(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    void *p; size_t n;
+    if (!get_bytes(env, argv[0], &p, &n)) return NULL;
+    if (!p || n % sizeof(ptmi_triangle)) { napi_throw_range_error(env, NULL, "expected a triangle blob (128-byte elements)"); return NULL; }
+    uint32_t nt = (uint32_t)(n / sizeof(ptmi_triangle));
+    uint32_t cap = ptmi_scene_bvh_node_bound(nt), count = 0, depth = 0;
+    void *nodes = NULL;
+    napi_value ab;
+    NAPI_OK(env, napi_create_arraybuffer(env, (size_t)cap * sizeof(ptmi_bvh_node), &nodes, &ab));
+    int rc = ptmi_scene_build_bvh((ptmi_triangle *)p, nt, 4, 12, (ptmi_bvh_node *)nodes, cap, &count, &depth);
+    if (rc) { napi_throw_error(env, "PTMI_SCENE", ptmi_scene_last_error()); return NULL; }
+    /* hand back exactly `count` nodes */
+    void *out = NULL;
+    napi_value ab2, obj, d;
+    NAPI_OK(env, napi_create_arraybuffer(env, (size_t)count * sizeof(ptmi_bvh_node), &out, &ab2));
+    memcpy(out, nodes, (size_t)count * sizeof(ptmi_bvh_node));
+    NAPI_OK(env, napi_create_object(env, &obj));
+    NAPI_OK(env, napi_create_uint32(env, depth, &d));
+    napi_set_named_property(env, obj, "nodes", ab2);
+    napi_set_named_property(env, obj, "depth", d);
+    return obj;
+}
+
+/* emissiveLights(triangles, materials, punctualLights) -> ArrayBuffer of 48-B lights: the punctual ones first,
+ * then one per emissive triangle in post-sort order (src/renderer/gpu.ts:121-138) */
+static napi_value js_emissive_lights(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return NULL;
+    void *pt, *pm, *pl; size_t nt, nm, nl;
+    if (!get_bytes(env, argv[0], &pt, &nt) || !get_bytes(env, argv[1], &pm, &nm) || !get_bytes(env, argv[2], &pl, &nl)) return NULL;
+    if (nt % sizeof(ptmi_triangle) || nm % sizeof(ptmi_material) || nl % sizeof(ptmi_light)) {
+        napi_throw_range_error(env, NULL, "blob length is not a multiple of its element size"); return NULL;
+    }
+    uint32_t ntri = (uint32_t)(nt / sizeof(ptmi_triangle)), n0 = (uint32_t)(nl / sizeof(ptmi_light)), count = n0;
+    uint32_t cap = n0 + ntri;
+    void *tmp = NULL;
+    napi_value ab;
+    NAPI_OK(env, napi_create_arraybuffer(env, (size_t)(cap ? cap : 1) * sizeof(ptmi_light), &tmp, &ab));
+    if (n0) memcpy(tmp, pl, nl);
+    if (ntri) {
+        int rc = ptmi_scene_emissive_lights((const ptmi_triangle *)pt, ntri, (const ptmi_material *)pm,
+                                            (uint32_t)(nm / sizeof(ptmi_material)), (ptmi_light *)tmp, cap, &count);
+        if (rc) { napi_throw_error(env, "PTMI_SCENE", ptmi_scene_last_error()); return NULL; }
+    }
+    void *out = NULL;
+    napi_value ab2;
+    NAPI_OK(env, napi_create_arraybuffer(env, (size_t)count * sizeof(ptmi_light), &out, &ab2));
+    if (count) memcpy(out, tmp, (size_t)count * sizeof(ptmi_light));
+    return ab2;
+}
+
 static napi_value js_abi_version(napi_env env, napi_callback_info info) {
     (void)info;
     napi_value v;
@@ -277,7 +335,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"uploadScene", js_upload_scene}, {"uploadAtlas", js_upload_atlas}, {"resize", js_resize},
         {"setOptions", js_set_options}, {"dispatch", js_dispatch}, {"synchronize", js_synchronize},
         {"readOutput", js_read_output}, {"writeOutput", js_write_output}, {"blit", js_blit}, {"getStats", js_get_stats},
-        {"resetStats", js_reset_stats},
+        {"resetStats", js_reset_stats}, {"buildBvh", js_build_bvh}, {"emissiveLights", js_emissive_lights},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

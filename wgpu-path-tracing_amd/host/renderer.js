@@ -53,14 +53,18 @@ Renderer.prototype.setupCamera = function () {
 Renderer.prototype.addOnUpdate = function (callback) { this.onUpdateTasks.push(callback); };
 
 /**
- * renderer.ts:130-134. `model` is a .ptscene path, {blobs, atlas} from readSceneFile, or a
- * SceneData object (gpu.ts:60-65) which is packed here like renderer.ts:282-320 does.
+ * renderer.ts:130-134. `model` is a .glb path (loaded and prepared like loader.ts + gpu.ts do), a
+ * .ptscene path, {blobs, atlas} from readSceneFile / prepareScene, or a SceneData object
+ * (gpu.ts:60-65) which is packed here like renderer.ts:282-320 does.
  */
 Renderer.prototype.loadModel = function (model, atlas) {
   var self = this;
   return new Promise(function (resolve) {
     var blobs;
-    if (typeof model === 'string') {
+    if (typeof model === 'string' && /\.glb$/i.test(model)) {
+      var prepared = require('./scene_prep').prepareScene(require('./gltf').loadGLB(model));
+      blobs = prepared.blobs; self.sceneInfo = prepared;
+    } else if (typeof model === 'string') {
       var f = sceneFile.readSceneFile(model);
       blobs = f.blobs; atlas = atlas || f.atlas;
     } else if (model.blobs) {
