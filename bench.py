@@ -98,6 +98,10 @@ def main():
     ap.add_argument("--frames-per-batch", type=int, default=0)
     ap.add_argument("--traversal", default="auto", choices=["auto", "global", "lds"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="dry run of the N>1 path on ONE GPU: every rank uses device 0, gloo backend, bands gathered "
+                         "through host memory, rank 0 checks the gathered frame bit for bit against its own unsharded "
+                         "render. Not a benchmark.")
     ap.add_argument("--timing", type=int, default=2, help="library HIP-event timing level (2 = every extend launch, 3 = every kernel)")
     args = ap.parse_args()
 
@@ -115,11 +119,16 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the path tracer has no CPU backend")
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     mis = 0 if args.no_mis else 1
     W, H = args.width, args.height * world
@@ -131,7 +140,12 @@ def main():
     ctx.resize(W, H)
     frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")       # binding 0, owned by the caller
     ctx.bind_output_device(frame.data_ptr(), frame.numel() * 4)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    # One explicit stream for rendering, copies and the collective. (torch's default stream has the NULL
+    # handle, which ptmi_set_stream reads as "use the context's own stream"; that stream is not ordered
+    # against torch work, so a gather could overtake the render.)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
     trav = {"auto": native.TRAVERSAL_AUTO, "global": native.TRAVERSAL_GLOBAL, "lds": native.TRAVERSAL_LDS}[args.traversal]
     ctx.set_options(max_bounces=args.bounces, do_mis=mis, tile_y0=y0, tile_y1=y1,
                     frames_per_batch=args.frames_per_batch, traversal=trav, cull=1, timing=args.timing)
@@ -143,7 +157,12 @@ def main():
         nonlocal frame_index
         ctx.dispatch(layout.make_camera(W, H, frame_index=frame_index), fps)
         frame_index += fps
-        if world > 1:
+        if world > 1 and args.rehearse:
+            host = frame.cpu()
+            shard.gather_bands(dist, host, H, world, rank)
+            if rank == 0:
+                frame.copy_(host)
+        elif world > 1:
             shard.gather_bands(dist, frame, H, world, rank)
 
     def fence():
@@ -162,7 +181,18 @@ def main():
     dt = time.perf_counter() - t0
 
     st = ctx.stats()
-    t = torch.tensor([dt, float(st.segments), float(st.shadow_rays), float(st.paths)], dtype=torch.float64, device="cuda")
+    rehearsal_ok = None
+    if args.rehearse and rank == 0:
+        # the same frames, unsharded, on this rank alone: the sharded + gathered frame must equal it bit for bit
+        gathered = frame.cpu().numpy().copy()
+        ctx.set_options(tile_y0=0, tile_y1=0, timing=0)
+        frame.zero_()
+        for k in range(args.warmup + args.steps):
+            ctx.dispatch(layout.make_camera(W, H, frame_index=k * fps), fps)
+        torch.cuda.synchronize()
+        rehearsal_ok = bool(np.array_equal(gathered.view(np.uint32), frame.cpu().numpy().view(np.uint32)))
+    t = torch.tensor([dt, float(st.segments), float(st.shadow_rays), float(st.paths)], dtype=torch.float64,
+                     device="cpu" if args.rehearse else "cuda")
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -188,6 +218,7 @@ def main():
                 "traversal": "lds" if st.traversal_used == native.TRAVERSAL_LDS else "global",
                 "triangles": int(len(scene.tris)), "bvh_nodes": int(len(scene.nodes)), "parallelism": f"rows x{world}",
             },
+            **({"rehearsal": {"sharded_equals_unsharded_bitwise": rehearsal_ok, "backend": "gloo", "note": "all ranks on one GPU; not a benchmark"}} if args.rehearse else {}),
             "segments": int(segments), "shadow_rays": int(shadow_rays), "paths": int(paths),
             "mean_path_length": round(mean_len, 4),
             "nominal_msamples": round(paths * args.bounces / dt / 1e6, 3),

@@ -27,7 +27,9 @@ def gather_bands(dist, frame, height, world, rank, dst=0):
     if len(sizes) == 1:
         # equal bands: gather straight into row views of the destination frame (concatenation)
         gl = [frame[a:b] for a, b in bands] if rank == dst else None
-        dist.gather(frame[y0:y1], gl, dst=dst)
+        # the destination's own band must not alias its slot in the gather list
+        mine = frame[y0:y1].clone() if rank == dst else frame[y0:y1]
+        dist.gather(mine, gl, dst=dst)
         return frame
     hmax = max(sizes)
     import torch
