@@ -48,11 +48,11 @@ struct ShadeParams {
     uint32_t bounce, max_bounces, do_mis;
 };
 
-enum { PT_VARIANT_GLOBAL = 1, PT_VARIANT_LDS = 2 };
+enum { PT_VARIANT_GLOBAL = 1, PT_VARIANT_LDS = 2, PT_VARIANT_LDS_NODES = 3 };
 
 struct TraverseConfig {
     int variant;            // PT_VARIANT_*
-    int stack_entries;      // 16, 32 or 64
+    int stack_entries;      // 14 (node cache only), 16, 32 or 64
     int cull;               // 0/1
     size_t lds_scene_bytes; // LDS variant: bytes of wnodes + tripos
 };
@@ -83,4 +83,3 @@ void pt_launch_blit(hipStream_t s, int blocks, uint32_t W, uint32_t H, const flo
                     uint32_t *out_rgba8);
 void pt_launch_math(hipStream_t s, int op, uint32_t n, const float *a, const float *b, const float *c, float *out);
 
-int pt_extend_set_lds_limit(size_t bytes);   // raises the dynamic-LDS cap of the LDS-variant kernels

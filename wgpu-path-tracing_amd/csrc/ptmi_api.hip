@@ -209,15 +209,21 @@ int build_image(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_
 
 int stack_entries_for(uint32_t depth) { return depth <= 17 ? 16 : depth <= 33 ? 32 : 64; }
 
-TraverseConfig traverse_config(const ptmi_ctx *c) {
+// closest_hit: the extend kernel may take the node-cache variant (two workgroups per CU) when it fits
+TraverseConfig traverse_config(const ptmi_ctx *c, bool closest_hit) {
     TraverseConfig cfg{};
     cfg.stack_entries = stack_entries_for(c->bvh_depth);
     cfg.cull = c->opt.cull ? 1 : 0;
     cfg.lds_scene_bytes = c->lds_scene_bytes;
-    bool fits = cfg.stack_entries <= 32 && c->lds_scene_bytes + (size_t)cfg.stack_entries * 1024 * 4 <= kLdsMax &&
-                c->sc.root_ref != PT_REF_NONE;
+    const bool have = c->sc.root_ref != PT_REF_NONE;
+    const bool fits = have && cfg.stack_entries <= 32 && c->lds_scene_bytes + (size_t)cfg.stack_entries * 1024 * 4 <= kLdsMax;
+    const int small_stack = c->bvh_depth <= 15 ? 14 : 16;       // the ordered descent pushes at most depth - 1 entries
+    const bool node_cache = have && c->bvh_depth <= 17 &&
+                            (size_t)c->sc.n_wnodes * 64 + (size_t)small_stack * 1024 * 4 <= kLdsMax / 2;
     if (c->opt.traversal == PTMI_TRAVERSAL_GLOBAL) cfg.variant = PT_VARIANT_GLOBAL;
-    else cfg.variant = fits ? PT_VARIANT_LDS : PT_VARIANT_GLOBAL;
+    else if (closest_hit && node_cache && c->opt.traversal == PTMI_TRAVERSAL_AUTO) {
+        cfg.variant = PT_VARIANT_LDS_NODES; cfg.stack_entries = small_stack;
+    } else cfg.variant = fits ? PT_VARIANT_LDS : PT_VARIANT_GLOBAL;
     return cfg;
 }
 
@@ -276,9 +282,6 @@ int ptmi_create(int device_ordinal, ptmi_ctx **out) {
         hipMalloc(&c->d_stats, kStatsWords * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(c->d_stats, 0, kStatsWords * sizeof(unsigned long long)) != hipSuccess) {
         ptmi_destroy(c); return fail(nullptr, PTMI_E_HIP, "device allocation failed");
-    }
-    if (pt_extend_set_lds_limit(kLdsMax) != 0) {
-        ptmi_destroy(c); return fail(nullptr, PTMI_E_HIP, "cannot raise the dynamic LDS limit to %zu bytes", kLdsMax);
     }
     *out = c;
     return PTMI_OK;
@@ -397,10 +400,10 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     if (npix * F > 0xFFFFFF00ull) return fail(c, PTMI_E_UNSUPPORTED, "batch of %llu paths exceeds 2^32", (unsigned long long)(npix * F));
     rc = ensure_capacity(c, (size_t)(npix * F));
     if (rc) return rc;
-    TraverseConfig cfg = traverse_config(c);
+    const TraverseConfig cfg = traverse_config(c, true), cfg_shadow = traverse_config(c, false);
     if (c->opt.traversal == PTMI_TRAVERSAL_LDS && cfg.variant != PT_VARIANT_LDS)
         return fail(c, PTMI_E_UNSUPPORTED, "scene needs %zu B of LDS plus the stack; it does not fit in %zu B", c->lds_scene_bytes, kLdsMax);
-    c->st.traversal_used = cfg.variant == PT_VARIANT_LDS ? PTMI_TRAVERSAL_LDS : PTMI_TRAVERSAL_GLOBAL;
+    c->st.traversal_used = cfg.variant == PT_VARIANT_GLOBAL ? PTMI_TRAVERSAL_GLOBAL : PTMI_TRAVERSAL_LDS;
     c->st.frames_per_batch_used = F;
     const int blocks = c->n_cu * 8;
     const int tiles = (int)(c->cap / pt_compact_tile_slots() + 1);
@@ -424,7 +427,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
                                   c->d_stats, b, last ? 0 : 1);
                 if (nee) {
                     Timed t(c, 3, t3);
-                    pt_launch_shadow(c->stream, blocks, cfg, c->sc, c->paths, c->sh, c->sq, &c->counts[kShadowCount], nullptr);
+                    pt_launch_shadow(c->stream, blocks, cfg_shadow, c->sc, c->paths, c->sh, c->sq, &c->counts[kShadowCount], nullptr);
                 }
                 cur ^= 1;
             }
@@ -568,7 +571,7 @@ int ptmi_debug_intersect(ptmi_ctx *c, uint32_t n, const float *o3, const float *
     rc = upload_rays(c, n, o3, d3, nullptr, c->paths.O, c->paths.D);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(&c->counts[0], &n, 4, hipMemcpyHostToDevice, c->stream));
-    TraverseConfig cfg = traverse_config(c);
+    TraverseConfig cfg = traverse_config(c, true);
     if (c->opt.traversal == PTMI_TRAVERSAL_LDS && cfg.variant != PT_VARIANT_LDS)
         return fail(c, PTMI_E_UNSUPPORTED, "scene does not fit in LDS");
     pt_launch_extend(c->stream, c->n_cu * 8, cfg, c->sc, c->paths, nullptr, &c->counts[0], c->hits);
@@ -593,7 +596,7 @@ int ptmi_debug_occluded(ptmi_ctx *c, uint32_t n, const float *o3, const float *d
     rc = upload_rays(c, n, o3, d3, dist, c->sh.SO, c->sh.SD);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(&c->counts[0], &n, 4, hipMemcpyHostToDevice, c->stream));
-    TraverseConfig cfg = traverse_config(c);
+    TraverseConfig cfg = traverse_config(c, false);
     pt_launch_shadow(c->stream, c->n_cu * 8, cfg, c->sc, c->paths, c->sh, nullptr, &c->counts[0], c->d_occ);
     HIP_TRY(c, hipMemcpyAsync(occ, c->d_occ, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

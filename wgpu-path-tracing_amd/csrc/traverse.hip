@@ -18,9 +18,10 @@
 // wave is not held hostage by its slowest ray. Per-ray work on Cornell varies 4x
 // around its mean (measured: max-over-64 / mean = 2.0), which is what this removes.
 //
-// Two memory variants share the body:
-//   global : wide nodes / triangle images read through L1/L2, per-lane stack in LDS
-//   lds    : the whole traversal image staged into LDS once per persistent workgroup
+// Three memory variants share the body:
+//   global     : wide nodes / triangle images read through L1/L2, per-lane stack in LDS
+//   lds        : the whole traversal image staged into LDS once per persistent workgroup
+//   node cache : only the wide nodes staged, so two workgroups share a CU
 #include "pt_device.h"
 #include "pt_math.h"
 
@@ -40,14 +41,17 @@ struct GlobalMem {
         a = p[0]; b = p[1]; c = p[2];
     }
 };
+// wide nodes in LDS; triangle images in LDS too (TRIS_IN_LDS) or read through L1/L2 (the node cache:
+// half the LDS, so two workgroups fit a CU)
+template <bool TRIS_IN_LDS>
 struct LdsMem {
-    const float4 *wn, *tp;      // LDS
+    const float4 *wn, *tp;
     PT_DEV void node(uint32_t i, float4 &a, float4 &b, float4 &c, float4 &d) const {
         const float4 *p = wn + 4u * i;
         a = p[0]; b = p[1]; c = p[2]; d = p[3];
     }
     PT_DEV void tri(uint32_t i, float4 &a, float4 &b, float4 &c) const {
-        const float4 *p = tp + 3u * i;
+        const float4 *p = TRIS_IN_LDS ? tp + 3u * i : tp + 3u * (size_t)i;
         a = p[0]; b = p[1]; c = p[2];
     }
 };
@@ -255,39 +259,55 @@ __global__ __launch_bounds__(GBLOCK) void k_trace_global(DevScene sc, IO io, con
 }
 
 // --------------------------------------------------------------------- LDS ----
-// One persistent 1024-thread workgroup per CU stages the traversal image
-// (wide nodes + triangle images) into LDS once, then its 16 waves walk their chunks.
+// Persistent 1024-thread workgroups stage the traversal image into LDS once, then their 16 waves walk
+// their share of the queue. Two footprints:
+//   full       wide nodes + triangle images + stacks (Cornell: 20 + 47 + 64 KB): one workgroup per CU
+//   node cache wide nodes + stacks only, triangle images through L1/L2: when that is <= 80 KB two
+//              workgroups fit a CU (8 waves per SIMD instead of 4)
+// Measured on Cornell 1080p: closest-hit rays run 14 % faster from the node cache (they are
+// issue-bound and gain from the second workgroup), shadow rays 7 % slower (they test fewer boxes per
+// triangle and miss the LDS-resident triangles); ptmi_api picks per kernel.
 constexpr int LBLOCK = 1024;
 
-template <int MODE, bool CULL, int STACK, class IO>
+template <int MODE, bool CULL, int STACK, bool TRIS_IN_LDS, class IO>
 __global__ __launch_bounds__(LBLOCK) void k_trace_lds(DevScene sc, IO io, const uint32_t *__restrict__ count_ptr) {
     extern __shared__ float4 smem[];
     const uint32_t count = *count_ptr;
     if (blockIdx.x * 64u >= count) return;      // wave 0 owns group blockIdx.x; if that is empty the whole group is idle
-    const uint32_t nw = 4u * sc.n_wnodes, nt = 3u * sc.n_tris;
+    const uint32_t nw = 4u * sc.n_wnodes, nt = TRIS_IN_LDS ? 3u * sc.n_tris : 0u;
     for (uint32_t i = threadIdx.x; i < nw; i += LBLOCK) smem[i] = sc.wnodes[i];
     for (uint32_t i = threadIdx.x; i < nt; i += LBLOCK) smem[nw + i] = sc.tripos[i];
     __syncthreads();
     const uint32_t gw = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;
     if (gw * 64u >= count) return;
-    LdsMem m{smem, smem + nw};
+    LdsMem<TRIS_IN_LDS> m{smem, TRIS_IN_LDS ? smem + nw : sc.tripos};
     uint32_t *stk = reinterpret_cast<uint32_t *>(smem + nw + nt) + threadIdx.x;
     trace_wave<MODE, CULL, STACK>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk, LBLOCK);
 }
 
-size_t lds_bytes(const TraverseConfig &cfg) {
-    return cfg.lds_scene_bytes + (size_t)cfg.stack_entries * LBLOCK * sizeof(uint32_t);
+template <int MODE, bool CULL, int STACK, bool TRIS, class IO>
+void launch_lds(hipStream_t s, int wgs, size_t bytes, const DevScene &sc, const IO &io, const uint32_t *count) {
+    // the default dynamic-LDS cap is 64 KB; raise it once per instantiation
+    static const hipError_t attr = hipFuncSetAttribute(
+        reinterpret_cast<const void *>(&k_trace_lds<MODE, CULL, STACK, TRIS, IO>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)attr;
+    hipLaunchKernelGGL((k_trace_lds<MODE, CULL, STACK, TRIS, IO>), dim3(wgs), dim3(LBLOCK), bytes, s, sc, io, count);
 }
 
 template <int MODE, bool CULL, class IO>
 void launch(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, const IO &io,
             const uint32_t *count) {
-    if (cfg.variant == PT_VARIANT_LDS) {
-        int lb = blocks / 8; if (lb < 1) lb = 1;               // one 1024-thread workgroup per CU
-        if (cfg.stack_entries <= 16)
-            hipLaunchKernelGGL((k_trace_lds<MODE, CULL, 16, IO>), dim3(lb), dim3(LBLOCK), lds_bytes(cfg), s, sc, io, count);
-        else
-            hipLaunchKernelGGL((k_trace_lds<MODE, CULL, 32, IO>), dim3(lb), dim3(LBLOCK), lds_bytes(cfg), s, sc, io, count);
+    const int cus = blocks / 8 > 0 ? blocks / 8 : 1;
+    const size_t stack_bytes = (size_t)cfg.stack_entries * LBLOCK * sizeof(uint32_t);
+    if (cfg.variant == PT_VARIANT_LDS_NODES) {                 // node cache, two workgroups per CU
+        const size_t bytes = (size_t)sc.n_wnodes * 64 + stack_bytes;
+        if (cfg.stack_entries <= 14) launch_lds<MODE, CULL, 14, false>(s, 2 * cus, bytes, sc, io, count);
+        else launch_lds<MODE, CULL, 16, false>(s, 2 * cus, bytes, sc, io, count);
+    } else if (cfg.variant == PT_VARIANT_LDS) {                // everything resident, one workgroup per CU
+        const size_t bytes = cfg.lds_scene_bytes + stack_bytes;
+        if (cfg.stack_entries <= 16) launch_lds<MODE, CULL, 16, true>(s, cus, bytes, sc, io, count);
+        else launch_lds<MODE, CULL, 32, true>(s, cus, bytes, sc, io, count);
     } else if (cfg.stack_entries <= 16) {
         hipLaunchKernelGGL((k_trace_global<MODE, CULL, 16, IO>), dim3(blocks), dim3(GBLOCK), 0, s, sc, io, count);
     } else if (cfg.stack_entries <= 32) {
@@ -297,24 +317,7 @@ void launch(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene
     }
 }
 
-template <int MODE, bool CULL, int STACK, class IO>
-hipError_t set_lds(size_t bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_lds<MODE, CULL, STACK, IO>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
-
 }  // namespace
-
-int pt_extend_set_lds_limit(size_t bytes) {
-    hipError_t e[] = {
-        set_lds<MODE_EXTEND, true, 16, ExtendIO>(bytes), set_lds<MODE_EXTEND, false, 16, ExtendIO>(bytes),
-        set_lds<MODE_EXTEND, true, 32, ExtendIO>(bytes), set_lds<MODE_EXTEND, false, 32, ExtendIO>(bytes),
-        set_lds<MODE_SHADOW, true, 16, ShadowIO>(bytes), set_lds<MODE_SHADOW, false, 16, ShadowIO>(bytes),
-        set_lds<MODE_SHADOW, true, 32, ShadowIO>(bytes), set_lds<MODE_SHADOW, false, 32, ShadowIO>(bytes),
-    };
-    for (hipError_t r : e) if (r != hipSuccess) return -1;
-    return 0;
-}
 
 void pt_launch_extend(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, DevPaths p,
                       const uint32_t *queue, const uint32_t *count, float4 *hits) {
