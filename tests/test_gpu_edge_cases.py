@@ -1,0 +1,131 @@
+"""Edge cases of the boundary on the GPU, each against the oracle bit for bit: empty and one-leaf scenes,
+1x1 and ragged image sizes, widths above 1000 (where the reference's seed x + 1000 y + 100000 frame aliases
+pixels), one bounce, zero frames, frame indices far from zero, lights-free scenes, resume from a saved buffer."""
+import numpy as np
+import pytest
+
+from ptmi import layout, scene_host, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+def render_both(gpu_ctx, oracle, sc, cam, frames, **opt):
+    o = dict(max_bounces=8, do_mis=1, tile_y0=0, tile_y1=0, frames_per_batch=0, cull=1, traversal=0)
+    o.update(opt)
+    gpu_ctx.upload_scene(sc)
+    gpu_ctx.resize(int(cam["width"]), int(cam["height"]))
+    gpu_ctx.set_options(**o)
+    gpu_ctx.reset_stats()
+    gpu_ctx.dispatch(cam, frames)
+    got, st = gpu_ctx.read_output(), gpu_ctx.stats()
+    ref, ost = oracle.render(sc, cam, frames, max_bounces=o["max_bounces"], do_mis=o["do_mis"])
+    assert (st.segments, st.shadow_rays) == (ost.segments, ost.shadow_rays)
+    assert same(got, ref)
+    return got, st
+
+
+def tiny_scene(n_tris):
+    """n_tris triangles of the Cornell floor/light (0 -> empty blobs; <= 4 -> the root is a leaf)."""
+    full = scenes.make("cornell")
+    mats = full.mats
+    if n_tris == 0:
+        return scenes.Scene("empty", np.zeros(0, layout.TRIANGLE), mats, np.zeros(0, layout.BVH_NODE),
+                            np.zeros(0, layout.LIGHT), None)
+    idx = np.r_[np.flatnonzero(full.tris["material_index"] == 3), np.flatnonzero(full.tris["material_index"] == 0)][:n_tris]
+    tris = np.ascontiguousarray(full.tris[idx])
+    nodes, depth = scene_host.build_bvh(tris)
+    return scenes.Scene(f"tiny{n_tris}", tris, mats, nodes, scene_host.emissive_lights(tris, mats), None, depth)
+
+
+def test_empty_scene_is_black(gpu_ctx, oracle):
+    got, st = render_both(gpu_ctx, oracle, tiny_scene(0), layout.make_camera(33, 17), 3)
+    assert not got.any() and st.segments == 33 * 17 * 3 and st.shadow_rays == 0
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 5])
+def test_root_leaf_and_smallest_trees(gpu_ctx, oracle, n):
+    sc = tiny_scene(n)
+    assert (len(sc.nodes) == 1) == (n <= 4)
+    got, _ = render_both(gpu_ctx, oracle, sc, layout.make_camera(40, 30, position=(0, 1.0, 1.5), aperture=0.0), 4)
+    assert got[..., :3].max() > 0          # the light quad is in view
+
+
+@pytest.mark.parametrize("W,H", [(1, 1), (1, 7), (7, 1), (63, 5), (65, 3), (1030, 4)])
+def test_ragged_sizes_and_seed_aliasing(gpu_ctx, oracle, scene_factory, W, H):
+    # 1030 wide: pixels (x + 1000, y) and (x, y + 1) share a seed (random.wgsl:3-5) — kept, not fixed
+    render_both(gpu_ctx, oracle, scene_factory("cornell"), layout.make_camera(W, H), 3)
+
+
+def test_one_bounce_no_mis_and_high_frame_index(gpu_ctx, oracle, scene_factory):
+    sc = scene_factory("cornell")
+    render_both(gpu_ctx, oracle, sc, layout.make_camera(48, 32), 2, max_bounces=1, do_mis=0)
+    render_both(gpu_ctx, oracle, sc, layout.make_camera(48, 32), 2, max_bounces=1, do_mis=1)
+    # frame index near the u32 wrap of frame * 100000 (42950 * 100000 > 2^32)
+    cam = layout.make_camera(32, 24, frame_index=42949)
+    gpu_ctx.upload_scene(sc)
+    gpu_ctx.resize(32, 24)
+    gpu_ctx.set_options(max_bounces=8, do_mis=1, tile_y0=0, tile_y1=0)
+    prev = np.random.default_rng(1).random((24, 32, 4)).astype(np.float32)
+    prev[..., 3] = 0
+    gpu_ctx.write_output(prev)
+    gpu_ctx.dispatch(cam, 3)
+    ref, _ = oracle.render(sc, cam, 3, out=prev.copy())
+    assert same(gpu_ctx.read_output(), ref)
+
+
+def test_zero_frames_and_resume(gpu_ctx, oracle, scene_factory):
+    sc = scene_factory("feature_box")
+    W, H = 40, 28
+    gpu_ctx.upload_scene(sc)
+    gpu_ctx.resize(W, H)
+    gpu_ctx.set_options(max_bounces=8, do_mis=1, tile_y0=0, tile_y1=0, frames_per_batch=0)
+    gpu_ctx.dispatch(layout.make_camera(W, H), 0)                       # a no-op
+    assert not gpu_ctx.read_output().any()
+    gpu_ctx.dispatch(layout.make_camera(W, H), 5)
+    saved = gpu_ctx.read_output()
+    gpu_ctx.resize(W, H)                                                # drops the buffer (renderer.ts:496-510)
+    assert not gpu_ctx.read_output().any()
+    gpu_ctx.write_output(saved)                                         # resume = buffer + frame index
+    gpu_ctx.dispatch(layout.make_camera(W, H, frame_index=5), 4)
+    ref, _ = oracle.render(sc, layout.make_camera(W, H), 9)
+    assert same(gpu_ctx.read_output(), ref)
+
+
+def test_scene_without_lights(gpu_ctx, oracle):
+    sc = scenes.make("cornell")
+    import copy
+    dark = copy.copy(sc)
+    dark.lights = np.zeros(0, layout.LIGHT)                             # emissive surfaces stay, NEE has nothing to pick
+    got, st = render_both(gpu_ctx, oracle, dark, layout.make_camera(48, 36), 4)
+    assert st.shadow_rays == 0 and got[..., :3].max() > 0
+
+
+def test_upload_validation_is_loud(gpu_ctx, scene_factory):
+    from ptmi import native
+    import copy
+    sc = scene_factory("cornell")
+    for mutate in (lambda s: s.nodes.__setitem__(0, s.nodes[5]),                       # root becomes a copy: a cycle-free but wrong tree
+                   lambda s: s.lights["triangle_index"].__setitem__(0, 10 ** 6),       # light -> missing triangle
+                   lambda s: s.lights["light_type"].__setitem__(0, 9)):                # unknown light type
+        bad = copy.copy(sc)
+        bad.nodes, bad.lights = sc.nodes.copy(), sc.lights.copy()
+        mutate(bad)
+        try:
+            gpu_ctx.upload_scene(bad)
+        except native.PtmiError:
+            continue
+        # a structurally valid (if different) tree may be accepted; it must then still render without faulting
+        gpu_ctx.resize(16, 16)
+        gpu_ctx.dispatch(layout.make_camera(16, 16), 1)
+        gpu_ctx.read_output()
+    leafy = copy.copy(sc)
+    leafy.nodes = sc.nodes.copy()
+    leaf = int(np.flatnonzero(leafy.nodes["triangle_count"] > 0)[0])
+    leafy.nodes["triangle_count"][leaf] = 40                                            # > 32 triangles in a leaf
+    with pytest.raises(native.PtmiError):
+        gpu_ctx.upload_scene(leafy)
+    gpu_ctx.upload_scene(sc)
