@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--frames-per-batch", type=int, default=0)
     ap.add_argument("--traversal", default="auto", choices=["auto", "global", "lds"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--keep-reference-tree", action="store_true",
+                    help="walk the BVH exactly as uploaded instead of the hierarchy rebuilt over its leaves")
     ap.add_argument("--rehearse", action="store_true",
                     help="dry run of the N>1 path on ONE GPU: every rank uses device 0, gloo backend, bands gathered "
                          "through host memory, rank 0 checks the gathered frame bit for bit against its own unsharded "
@@ -136,6 +138,7 @@ def main():
     scene = scenes.make(args.scene)
 
     ctx = native.Context(local_rank)
+    ctx.set_options(keep_reference_tree=int(args.keep_reference_tree))
     ctx.upload_scene(scene)
     ctx.resize(W, H)
     frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")       # binding 0, owned by the caller

@@ -56,7 +56,10 @@ typedef struct ptmi_options {
     uint32_t timing;            /* 0: none; 1: HIP events around each dispatch (gpu_ms); 2: also around every
                                    extend launch (extend_ms); 3: also around every shade and shadow launch.
                                    Each event pair costs a few microseconds of stream time. */
-    uint32_t reserved[8];
+    uint32_t keep_reference_tree; /* read by ptmi_upload_scene. 0 (default): when every node box of the uploaded BVH contains
+                                   its children's boxes, traversal walks a SAH hierarchy rebuilt over the SAME leaves (same
+                                   results, about half the box tests); 1: always walk the tree as uploaded */
+    uint32_t reserved[7];
 } ptmi_options;
 
 typedef struct ptmi_stats {

@@ -104,6 +104,64 @@ def test_extend_parity(gpu_ctx, oracle, scene_factory, name, cull, trav):
     gpu_ctx.set_options(cull=1, traversal=native.TRAVERSAL_AUTO)
 
 
+@pytest.mark.parametrize("name", ["cornell", "feature_box", "cornell_spheres"])
+@pytest.mark.parametrize("keep", [0, 1])
+def test_irregular_rays_parity(gpu_ctx, oracle, scene_factory, name, keep):
+    """Rays with zero / subnormal direction components, started exactly on box planes and triangle vertices:
+    the cases where the slab test produces inf and NaN (pt.wgsl:235-236). The rebuilt hierarchy must not be
+    used for them (csrc/fast_tree.hip); with keep_reference_tree=1 nothing is rebuilt at all."""
+    sc = scene_factory(name)
+    gpu_ctx.set_options(keep_reference_tree=keep, cull=1, traversal=0)
+    gpu_ctx.upload_scene(sc)
+    rng = np.random.default_rng(21)
+    n = 60_000
+    corners = np.concatenate([sc.nodes["aabb_min"], sc.nodes["aabb_max"], sc.tris["v0"], sc.tris["v1"], sc.tris["v2"]])
+    o = corners[rng.integers(0, len(corners), n)].astype(np.float32)
+    mix = rng.integers(0, 3, n)
+    o[mix == 1] += (rng.standard_normal((int((mix == 1).sum()), 3)) * 0.3).astype(np.float32)
+    d = rng.standard_normal((n, 3)).astype(np.float32)
+    kind = rng.integers(0, 5, n)
+    axis = rng.integers(0, 3, n)
+    rows = np.arange(n)
+    d[kind == 0] = 0.0
+    d[rows[kind == 0], axis[kind == 0]] = rng.choice([-1.0, 1.0], int((kind == 0).sum()))       # axis-parallel
+    d[rows[kind == 1], axis[kind == 1]] = 0.0                                                    # one exact zero
+    d[rows[kind == 2], axis[kind == 2]] = -0.0                                                   # one negative zero
+    d[rows[kind == 3], axis[kind == 3]] = np.float32(1e-41)                                      # subnormal: 1/d = inf
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30).astype(np.float32)
+    d[rows[kind == 3], axis[kind == 3]] = np.float32(1e-41)
+    gt, gtri, gu, gv = gpu_ctx.debug_intersect(o, d)
+    ot, otri, ou, ov, _ = oracle.intersect(sc, o, d)
+    assert 0.05 < (ot > 0).mean() < 1.0
+    assert np.array_equal(gtri, otri), f"{(gtri != otri).sum()} triangle ids differ"
+    assert_same_floats(gt, ot, "t")
+    assert_same_floats(gu, ou, "u")
+    dist = (rng.random(n) * 2.0).astype(np.float32)
+    dist[::3] = -1
+    assert np.array_equal(gpu_ctx.debug_occluded(o, d, dist), oracle.occluded(sc, o, d, dist))
+    gpu_ctx.set_options(keep_reference_tree=0)
+    gpu_ctx.upload_scene(sc)
+
+
+def test_rebuilt_hierarchy_equals_uploaded_tree(gpu_ctx, scene_factory):
+    """Same frames with the hierarchy rebuilt over the reference's leaves and with the tree exactly as uploaded,
+    cull on and off: four renders, one bit pattern (the size-independent form of the equivalence argument)."""
+    sc = scene_factory("cornell_spheres")
+    W, H = 256, 144
+    outs = []
+    for keep in (0, 1):
+        for cull in (1, 0):
+            gpu_ctx.set_options(keep_reference_tree=keep, cull=cull, max_bounces=8, do_mis=1, tile_y0=0, tile_y1=0,
+                                frames_per_batch=0, traversal=0)
+            gpu_ctx.upload_scene(sc)
+            gpu_ctx.resize(W, H)
+            gpu_ctx.dispatch(layout.make_camera(W, H), 8)
+            outs.append(gpu_ctx.read_output())
+    for o in outs[1:]:
+        assert np.array_equal(bits(o), bits(outs[0]))
+    gpu_ctx.set_options(keep_reference_tree=0, cull=1)
+
+
 @pytest.mark.parametrize("name", ["cornell", "feature_box"])
 def test_occluded_parity(gpu_ctx, oracle, scene_factory, name):
     sc = scene_factory(name)

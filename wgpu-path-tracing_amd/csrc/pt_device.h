@@ -26,10 +26,14 @@ struct DevScene {
     const ptmi_material *mats;  uint32_t n_mats;
     const ptmi_light *lights;   uint32_t n_lights;
     const void *atlas;          uint32_t atlas_w, atlas_h, atlas_fmt;   // 0 none, 1 rgba16f, 2 rgba32f
-    const float4 *wnodes;       uint32_t n_wnodes;
+    const float4 *wnodes;       uint32_t n_wnodes;     // the hierarchy the kernels walk
     const float4 *tripos;
     float root_min[3], root_max[3];
     uint32_t root_ref;          // PT_REF_NONE: empty scene
+    // When the reference tree is nested (every node box contains its children) the walked hierarchy is a
+    // SAH tree rebuilt over the reference's leaves (fast_tree.hip, has_fast = 1) and the reference-shaped
+    // image is kept for irregular rays; otherwise wnodes IS the reference-shaped image.
+    const float4 *ref_wnodes;   uint32_t ref_root_ref, has_fast;
 };
 
 // ---- path state: 64 B per path, four float4 streams indexed by path id ----

@@ -5,6 +5,7 @@
 // createBuffers :242-355, createBindGroups :368-381, updateCamera + dispatch :403-431).
 #include "ptmi.h"
 #include "pt_device.h"
+#include "fast_tree.h"
 
 #include <algorithm>
 #include <cmath>
@@ -31,7 +32,7 @@ struct ptmi_ctx {
 
     // scene (bindings 1, 2, 4, 5, 6)
     void *d_tris = nullptr, *d_mats = nullptr, *d_lights = nullptr, *d_atlas = nullptr;
-    float4 *d_wnodes = nullptr, *d_tripos = nullptr;
+    float4 *d_wnodes = nullptr, *d_tripos = nullptr, *d_fast_wnodes = nullptr;
     DevScene sc{};
     uint32_t bvh_depth = 0;
     bool have_scene = false;
@@ -140,9 +141,11 @@ int ensure_capacity(ptmi_ctx *c, size_t n) {
 
 // ---- scene validation and the traversal image ---------------------------------
 struct Built {
-    std::vector<float4> wnodes, tripos;
+    std::vector<float4> wnodes, tripos;      // reference-shaped image
+    std::vector<float4> fast_wnodes;         // SAH tree over the reference's leaves (empty: not applicable)
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
     uint32_t root_ref = PT_REF_NONE, depth = 0;
+    uint32_t fast_root = PT_REF_NONE, fast_depth = 0;
 };
 
 uint32_t leaf_ref(const ptmi_bvh_node &n) {
@@ -196,6 +199,27 @@ int build_image(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_
     }
     for (int k = 0; k < 3; k++) { b.root_min[k] = nodes[0].aabb_min[k]; b.root_max[k] = nodes[0].aabb_max[k]; }
     b.root_ref = ref_of(0);
+    // Nested tree (each node box contains its children's, all finite)? Then rebuild the hierarchy over the
+    // reference's leaves (fast_tree.hip explains why the results cannot change).
+    bool nested = n_wide > 0;
+    std::vector<PtFastLeaf> leaves;
+    for (uint32_t i = 0; i < nn && nested; i++) {
+        if (!seen[i]) continue;
+        const ptmi_bvh_node &n = nodes[i];
+        for (int k = 0; k < 3; k++) nested = nested && std::isfinite(n.aabb_min[k]) && std::isfinite(n.aabb_max[k]);
+        if (n.triangle_count > 0) {
+            PtFastLeaf l;
+            for (int k = 0; k < 3; k++) { l.mn[k] = n.aabb_min[k]; l.mx[k] = n.aabb_max[k]; }
+            l.ref = leaf_ref(n); l.weight = n.triangle_count;
+            leaves.push_back(l);
+        } else {
+            for (uint32_t ch : {n.left, n.right})
+                for (int k = 0; k < 3; k++)
+                    nested = nested && nodes[ch].aabb_min[k] >= n.aabb_min[k] && nodes[ch].aabb_max[k] <= n.aabb_max[k];
+        }
+    }
+    if (nested && leaves.size() >= 2 && !c->opt.keep_reference_tree)
+        pt_build_fast_tree(leaves, b.fast_wnodes, b.fast_root, b.fast_depth);
     // triangle images: v0, e1 = v1 - v0, e2 = v2 - v0 (pt.wgsl:128-129; one IEEE subtraction each)
     b.tripos.resize((size_t)nt * 3);
     for (uint32_t i = 0; i < nt; i++) {
@@ -295,6 +319,7 @@ int ptmi_destroy(ptmi_ctx *c) {
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     free_batch(c);
     dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_atlas); dfree(c->d_wnodes); dfree(c->d_tripos);
+    dfree(c->d_fast_wnodes);
     dfree(c->d_out_own); dfree(c->counts); dfree(c->d_stats);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -317,7 +342,7 @@ int ptmi_upload_scene(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const
     int rc = build_image(c, tris, nt, nodes, nn, b);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_wnodes); dfree(c->d_tripos);
+    dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_wnodes); dfree(c->d_tripos); dfree(c->d_fast_wnodes);
     auto up = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
         if (bytes == 0) { bytes = 16; hipError_t e = hipMalloc(dst, bytes); if (e != hipSuccess) return e; return hipMemset(*dst, 0, bytes); }
         hipError_t e = hipMalloc(dst, bytes); if (e != hipSuccess) return e;
@@ -328,16 +353,20 @@ int ptmi_upload_scene(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const
     HIP_TRY(c, up(&c->d_lights, lights, (size_t)nl * sizeof(ptmi_light)));
     HIP_TRY(c, up(reinterpret_cast<void **>(&c->d_wnodes), b.wnodes.data(), b.wnodes.size() * 16));
     HIP_TRY(c, up(reinterpret_cast<void **>(&c->d_tripos), b.tripos.data(), b.tripos.size() * 16));
+    const bool fast = !b.fast_wnodes.empty();
+    if (fast) HIP_TRY(c, up(reinterpret_cast<void **>(&c->d_fast_wnodes), b.fast_wnodes.data(), b.fast_wnodes.size() * 16));
     DevScene &s = c->sc;
     s.tris = static_cast<const ptmi_triangle *>(c->d_tris); s.n_tris = nt;
     s.mats = static_cast<const ptmi_material *>(c->d_mats); s.n_mats = nm;
     s.lights = static_cast<const ptmi_light *>(c->d_lights); s.n_lights = nl;
-    s.wnodes = c->d_wnodes; s.n_wnodes = (uint32_t)(b.wnodes.size() / 4);
+    s.ref_wnodes = c->d_wnodes; s.ref_root_ref = b.root_ref; s.has_fast = fast ? 1u : 0u;
+    s.wnodes = fast ? c->d_fast_wnodes : c->d_wnodes;
+    s.n_wnodes = (uint32_t)((fast ? b.fast_wnodes.size() : b.wnodes.size()) / 4);
     s.tripos = c->d_tripos;
     for (int k = 0; k < 3; k++) { s.root_min[k] = b.root_min[k]; s.root_max[k] = b.root_max[k]; }
-    s.root_ref = b.root_ref;
-    c->bvh_depth = b.depth;
-    c->lds_scene_bytes = b.wnodes.size() * 16 + b.tripos.size() * 16;
+    s.root_ref = fast ? b.fast_root : b.root_ref;
+    c->bvh_depth = std::max(b.depth, b.fast_depth);           // stacks must hold either tree (irregular rays use the uploaded one)
+    c->lds_scene_bytes = (size_t)s.n_wnodes * 64 + b.tripos.size() * 16;
     c->have_scene = true;
     return PTMI_OK;
 }

@@ -136,7 +136,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
     const uint32_t ngroups = (count + 63u) >> 6;
     const uint32_t end = gw < ngroups ? ((ngroups - gw + total_waves - 1u) / total_waves) * 64u : 0u;   // virtual slots
     uint32_t next = 0u;                     // wave-uniform virtual index
-    bool active = false;
+    bool active = false, use_ref = false;
     uint32_t slot = 0, cur = 0, tri_i = 0, tri_e = 0;
     int sp = 0;
     v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), inv = mk3(0, 0, 0);
@@ -169,11 +169,16 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                 sp = 0;
                 limit = (ANY && CULL && !(tlim < 0.0f)) ? cull_limit(tlim) : __builtin_inff();
                 float tm;
+                // The rebuilt hierarchy is exact for regular rays only (fast_tree.hip): a ray with a zero,
+                // subnormal or non-finite direction component walks the reference's own tree instead.
+                const bool regular = __builtin_isfinite(inv.x) & __builtin_isfinite(inv.y) & __builtin_isfinite(inv.z) &
+                                     (inv.x != 0.0f) & (inv.y != 0.0f) & (inv.z != 0.0f);
+                use_ref = sc.has_fast != 0u && !regular;
                 if (sc.root_ref != PT_REF_NONE &&
                     slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2],
                          o, inv, tm)) {
                     active = true;
-                    enter(sc.root_ref);
+                    enter(use_ref ? sc.ref_root_ref : sc.root_ref);
                 } else {
                     io.finish(slot, best, false);              // misses the root box: nothing is tested (pt.wgsl:266)
                 }
@@ -216,7 +221,12 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
             }
         } else if (active && !at_leaf) {
             float4 a, b, c, r;
-            m.node(cur, a, b, c, r);
+            if (use_ref) {                                  // irregular ray: the reference's tree, from global memory
+                const float4 *p = sc.ref_wnodes + 4u * (size_t)cur;
+                a = p[0]; b = p[1]; c = p[2]; r = p[3];
+            } else {
+                m.node(cur, a, b, c, r);
+            }
             float tl, tr;
             bool hl = slab(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, tl);
             bool hr = slab(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, tr);

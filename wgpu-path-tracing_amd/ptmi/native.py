@@ -35,7 +35,8 @@ class Options(ctypes.Structure):
     _fields_ = [("max_bounces", ctypes.c_uint32), ("do_mis", ctypes.c_uint32),
                 ("tile_y0", ctypes.c_uint32), ("tile_y1", ctypes.c_uint32),
                 ("frames_per_batch", ctypes.c_uint32), ("traversal", ctypes.c_uint32),
-                ("cull", ctypes.c_uint32), ("timing", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 8)]
+                ("cull", ctypes.c_uint32), ("timing", ctypes.c_uint32), ("keep_reference_tree", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32 * 7)]
 
 
 class Stats(ctypes.Structure):
