@@ -177,7 +177,7 @@ int build_image(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_
         if (seen[it.node]) return fail(c, PTMI_E_INVALID, "BVH node %u is reachable twice", it.node);
         seen[it.node] = 1;
         b.depth = std::max(b.depth, it.depth);
-        if (it.depth > 65) return fail(c, PTMI_E_UNSUPPORTED, "BVH deeper than 65 levels (the reference's 64-entry stack, pt.wgsl:249)");
+        if (it.depth > 62) return fail(c, PTMI_E_UNSUPPORTED, "BVH deeper than 62 levels (the reference's own traversal stack holds 64 entries, pt.wgsl:249)");
         const ptmi_bvh_node &n = nodes[it.node];
         if (n.triangle_count > 0) { int rc = check_leaf(it.node); if (rc) return rc; continue; }
         wide_of[it.node] = n_wide++;
@@ -231,7 +231,8 @@ int build_image(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_
     return PTMI_OK;
 }
 
-int stack_entries_for(uint32_t depth) { return depth <= 17 ? 16 : depth <= 33 ? 32 : 64; }
+// per-lane LDS entries: the node stack (<= depth - 2 deferred siblings) plus room for filed leaves
+int stack_entries_for(uint32_t depth) { return depth + 2 <= 16 ? 16 : depth + 2 <= 32 ? 32 : 64; }
 
 // closest_hit: the extend kernel may take the node-cache variant (two workgroups per CU) when it fits
 TraverseConfig traverse_config(const ptmi_ctx *c, bool closest_hit) {
@@ -241,8 +242,8 @@ TraverseConfig traverse_config(const ptmi_ctx *c, bool closest_hit) {
     cfg.lds_scene_bytes = c->lds_scene_bytes;
     const bool have = c->sc.root_ref != PT_REF_NONE;
     const bool fits = have && cfg.stack_entries <= 32 && c->lds_scene_bytes + (size_t)cfg.stack_entries * 1024 * 4 <= kLdsMax;
-    const int small_stack = c->bvh_depth <= 15 ? 14 : 16;       // the ordered descent pushes at most depth - 1 entries
-    const bool node_cache = have && c->bvh_depth <= 17 &&
+    const int small_stack = c->bvh_depth + 1 <= 15 ? 15 : 16;  // node stack <= depth - 2, plus >= 3 entries for filed leaves
+    const bool node_cache = have && c->bvh_depth + 2 <= 16 &&
                             (size_t)c->sc.n_wnodes * 64 + (size_t)small_stack * 1024 * 4 <= kLdsMax / 2;
     if (c->opt.traversal == PTMI_TRAVERSAL_GLOBAL) cfg.variant = PT_VARIANT_GLOBAL;
     else if (closest_hit && node_cache && c->opt.traversal == PTMI_TRAVERSAL_AUTO) {
