@@ -163,6 +163,7 @@ static napi_value js_set_options(napi_env env, napi_callback_info info) {
     o.traversal = get_u32_prop(env, argv[1], "traversal", o.traversal);
     o.cull = get_u32_prop(env, argv[1], "cull", o.cull);
     o.timing = get_u32_prop(env, argv[1], "timing", o.timing);
+    o.keep_reference_tree = get_u32_prop(env, argv[1], "keepReferenceTree", o.keep_reference_tree);
     int rc = ptmi_set_options(ctx, &o);
     if (rc) return throw_ptmi(env, ctx, rc, "ptmi_set_options");
     return NULL;

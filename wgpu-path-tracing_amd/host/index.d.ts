@@ -22,7 +22,7 @@ export interface SceneBlobs { triangles: ArrayBuffer; materials: ArrayBuffer; bv
 export interface Atlas { data: ArrayBuffer; width: number; height: number; format: 1 | 2; }
 export interface TraceOptions {
   maxBounces?: number; doMis?: number; tileY0?: number; tileY1?: number; framesPerBatch?: number;
-  traversal?: 0 | 1 | 2; cull?: number; timing?: number;
+  traversal?: 0 | 1 | 2; cull?: number; timing?: number; keepReferenceTree?: number;
 }
 export interface Stats {
   paths: number; segments: number; shadowRays: number; frames: number; dispatches: number;
