@@ -10,13 +10,15 @@
 // traversal — the minimum t over all triangles in leaves whose ancestors all pass
 // the slab test, ties to the lowest triangle index (= first in the reference's
 // left-first DFS) — reached by an ordered two-box-per-step descent with a
-// conservative distance cull. cull = 0 visits exactly the reference's leaf set.
+// conservative distance cull, over a hierarchy rebuilt on the reference's leaves
+// (fast_tree.hip) or the tree exactly as uploaded. cull = 0 tests exactly the
+// reference's leaf set.
 //
-// Execution model: PERSISTENT WAVES. A wave owns a contiguous chunk of the ray queue
-// and keeps 64 rays in flight; when enough lanes have finished their ray, the idle
-// lanes fetch the next rays of the chunk (rank by ballot/popcount, no atomics), so a
-// wave is not held hostage by its slowest ray. Per-ray work on Cornell varies 4x
-// around its mean (measured: max-over-64 / mean = 2.0), which is what this removes.
+// Execution model: PERSISTENT WAVES. A wave owns a strided share of the ray queue and
+// keeps 64 rays in flight; when enough lanes have finished their ray, the idle lanes
+// fetch the wave's next rays (rank by ballot/popcount, no atomics), so a wave is not
+// held hostage by its slowest ray. Per-ray work on Cornell varies widely (measured:
+// max-over-64 / mean = 2.0), which is what this removes.
 //
 // Three memory variants share the body:
 //   global     : wide nodes / triangle images read through L1/L2, per-lane stack in LDS
@@ -24,6 +26,7 @@
 //   node cache : only the wide nodes staged, so two workgroups share a CU
 #include "pt_device.h"
 #include "pt_math.h"
+#include <atomic>
 
 namespace {
 
@@ -292,11 +295,16 @@ __global__ __launch_bounds__(LBLOCK) void k_trace_lds(DevScene sc, IO io, const 
 
 template <int MODE, bool CULL, int STACK, bool TRIS, class IO>
 void launch_lds(hipStream_t s, int wgs, size_t bytes, const DevScene &sc, const IO &io, const uint32_t *count) {
-    // the default dynamic-LDS cap is 64 KB; raise it once per instantiation
-    static const hipError_t attr = hipFuncSetAttribute(
-        reinterpret_cast<const void *>(&k_trace_lds<MODE, CULL, STACK, TRIS, IO>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)attr;
+    // the default dynamic-LDS cap is 64 KB; raise it once per instantiation and device
+    static std::atomic<uint64_t> raised{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(raised.load(std::memory_order_relaxed) & bit)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_lds<MODE, CULL, STACK, TRIS, IO>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised.fetch_or(bit, std::memory_order_relaxed);
+    }
     hipLaunchKernelGGL((k_trace_lds<MODE, CULL, STACK, TRIS, IO>), dim3(wgs), dim3(LBLOCK), bytes, s, sc, io, count);
 }
 
