@@ -1,0 +1,264 @@
+"""The Node host's texture path: host/png_decode.js + host/atlas.js restate what
+src/renderer/atlas.ts does with the browser's image decoder, potpack@2.0.0 and a 2-D canvas, and
+host/scene_prep.js writes the rectangles into the material blob (gpu.ts:401-419). Checked against the
+independent numpy restatement in tests/atlas_ref.py, byte for byte (CPU only)."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import atlas_ref
+from ptmi import glb_io, layout, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "wgpu-path-tracing_amd", "host")
+NODE = shutil.which("node")
+pytestmark = pytest.mark.skipif(NODE is None, reason="node is not installed")
+
+
+def node(script, *args):
+    return subprocess.check_output([NODE, "-e", script, *map(str, args)], cwd=HOST, text=True)
+
+
+def _build():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "wgpu-path-tracing_amd"), "all"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(HOST, "addon")], stdout=subprocess.DEVNULL)
+
+
+DECODE = """
+var fs = require('fs'), d = require('./png_decode').decodePNG(fs.readFileSync(process.argv[1]));
+fs.writeFileSync(process.argv[2], Buffer.from(d.data.buffer, d.data.byteOffset, d.data.byteLength));
+console.log(d.width + ' ' + d.height);
+"""
+
+
+def _decode(tmp_path, name, data):
+    src, dst = tmp_path / (name + ".png"), tmp_path / (name + ".rgba")
+    src.write_bytes(data)
+    w, h = map(int, node(DECODE, src, dst).split())
+    return np.fromfile(dst, np.uint8).reshape(h, w, 4)
+
+
+def test_png_decoder_all_colour_types_and_filters(tmp_path):
+    rng = np.random.default_rng(7)
+    h, w = 11, 13                                     # odd sizes: sub-byte rows end mid-byte
+    rgba = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    ones = np.full((h, w, 1), 255, np.uint8)
+    # truecolour + alpha, every filter type in turn (default filter cycle) and each one alone
+    assert np.array_equal(_decode(tmp_path, "rgba", glb_io.encode_png(rgba)), rgba)
+    for f in range(5):
+        assert np.array_equal(_decode(tmp_path, "f%d" % f, glb_io.encode_png(rgba, filters=[f] * h)), rgba)
+    # truecolour
+    assert np.array_equal(_decode(tmp_path, "rgb", glb_io.encode_png(rgba[..., :3], 2)), np.concatenate([rgba[..., :3], ones], 2))
+    # grey and grey + alpha
+    g = rgba[..., :1]
+    assert np.array_equal(_decode(tmp_path, "g", glb_io.encode_png(g, 0)), np.concatenate([g, g, g, ones], 2))
+    ga = rgba[..., :2]
+    assert np.array_equal(_decode(tmp_path, "ga", glb_io.encode_png(ga, 4)), np.concatenate([g, g, g, ga[..., 1:]], 2))
+    # palette at every depth, with tRNS on the first entries
+    for depth in (1, 2, 4, 8):
+        n = 1 << depth
+        pal = rng.integers(0, 256, (n, 3), dtype=np.uint8)
+        trns = rng.integers(0, 256, max(1, n // 2), dtype=np.uint8)
+        idx = rng.integers(0, n, (h, w), dtype=np.uint8)
+        alpha = np.full(n, 255, np.uint8)
+        alpha[:len(trns)] = trns
+        want = np.concatenate([pal[idx], alpha[idx][..., None]], 2)
+        got = _decode(tmp_path, "p%d" % depth, glb_io.encode_png(idx, 3, palette=pal, trns=trns, depth=depth))
+        assert np.array_equal(got, want), depth
+    # low-depth grey scales to 0..255
+    for depth in (1, 2, 4):
+        v = rng.integers(0, 1 << depth, (h, w), dtype=np.uint8)
+        s = np.round(v.astype(np.float64) * 255 / ((1 << depth) - 1)).astype(np.uint8)[..., None]
+        got = _decode(tmp_path, "g%d" % depth, glb_io.encode_png(v, 0, depth=depth))
+        assert np.array_equal(got, np.concatenate([s, s, s, ones], 2)), depth
+
+
+def test_png_decoder_rejects_garbage(tmp_path):
+    bad = tmp_path / "bad.png"
+    bad.write_bytes(b"not a png at all")
+    r = subprocess.run([NODE, "-e", DECODE, str(bad), str(tmp_path / "o")], cwd=HOST, capture_output=True, text=True)
+    assert r.returncode != 0 and "not a PNG" in r.stderr
+
+
+POTPACK = """
+var fs = require('fs'), boxes = JSON.parse(fs.readFileSync(process.argv[1], 'utf8'));
+boxes.forEach(function (b, i) { b.id = i; });
+var r = require('./atlas').potpack(boxes);
+console.log(JSON.stringify({ w: r.w, h: r.h, boxes: boxes }));
+"""
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_potpack_matches_restatement(tmp_path, seed):
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(1, 40))
+    sizes = [(float(rng.integers(0, 9) * 0.5 * (1 << int(rng.integers(0, 6)))), float(rng.integers(0, 9) * 0.5 * (1 << int(rng.integers(0, 6)))))
+             for _ in range(n)]
+    if seed == 0:
+        sizes += [(0.0, 0.0)] * 4 + [(64.0, 64.0)] * 3          # empty boxes and exact fits
+    boxes = [{"w": w, "h": h} for w, h in sizes]
+    p = tmp_path / "boxes.json"
+    p.write_text(json.dumps(boxes))
+    got = json.loads(node(POTPACK, p))
+    mine = [dict(b, id=i) for i, b in enumerate(boxes)]
+    w, h = atlas_ref.potpack(mine)
+    assert (got["w"], got["h"]) == (w, h)
+    want = {b["id"]: (b.get("x", 0), b.get("y", 0)) for b in mine}
+    for b in got["boxes"]:
+        assert (b.get("x", 0), b.get("y", 0)) == want[b["id"]], b
+    # and the packing is a packing: inside the bounds, no two non-empty boxes overlap
+    real = [b for b in got["boxes"] if b["w"] > 0 and b["h"] > 0]
+    for i, a in enumerate(real):
+        assert a["x"] >= 0 and a["y"] >= 0 and a["x"] + a["w"] <= w and a["y"] + a["h"] <= h
+        for b in real[i + 1:]:
+            assert (a["x"] + a["w"] <= b["x"] or b["x"] + b["w"] <= a["x"] or a["y"] + a["h"] <= b["y"] or b["y"] + b["h"] <= a["y"])
+
+
+def test_unorm8_to_half_table():
+    got = json.loads(node("var a = require('./atlas'), u = new Uint8Array(256); for (var i = 0; i < 256; i++) u[i] = i;"
+                          "console.log(JSON.stringify(Array.from(a.canvasToHalf(u))));"))
+    want = (np.arange(256, dtype=np.float32) / np.float32(255)).astype(np.float16).view(np.uint16)
+    assert np.array_equal(np.array(got, np.uint16), want)
+    # toHalf on the awkward cases: ties, subnormals, overflow, inf/nan
+    vals = [0.0, -0.0, 1.0, 65504.0, 65520.0, 1e-8, 5.96e-8, 6.1e-5, 2.0 ** -24, 2.0 ** -25, 1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11,
+            float("inf"), -float("inf"), 0.1, -1234.5678]
+    got = json.loads(node("var a = require('./atlas'); console.log(JSON.stringify(JSON.parse(process.argv[1]).map("
+                          "function (v) { return a.toHalf(v === 'inf' ? Infinity : v === '-inf' ? -Infinity : v); })));",
+                          json.dumps(["inf" if v == float("inf") else "-inf" if v == -float("inf") else v for v in vals])))
+    with np.errstate(over="ignore"):
+        want = np.array(vals, np.float32).astype(np.float16).view(np.uint16)
+    assert np.array_equal(np.array(got, np.uint16), want)
+
+
+def _textured_glb(path, rng, sizes, odd=False):
+    """Two quads + a light panel; material 0 uses albedo + normal + pbr + emissive images, material 1 shares
+    image 0 as its albedo, material 2 (the light) has no textures, material 3 is unused by any mesh."""
+    images = []
+    for k, (w, h) in enumerate(sizes):
+        px = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        if k != 1:
+            px[..., 3] = 255                        # image 1 keeps a varying alpha
+        images.append(px)
+    quad = lambda a, b, c, d, n: scenes._quad(a, b, c, d, n, 0)
+
+    def mesh_of(tris, material):
+        pos = np.stack([tris["v0"], tris["v1"], tris["v2"]], 1).reshape(-1, 3)
+        nrm = np.stack([tris["n0"], tris["n1"], tris["n2"]], 1).reshape(-1, 3)
+        uv = np.stack([tris["uv0"], tris["uv1"], tris["uv2"]], 1).reshape(-1, 2)
+        return {"positions": pos, "normals": nrm, "uvs": uv, "indices": np.arange(len(pos)), "material": material}
+
+    floor = quad((-1, 0, -1), (1, 0, -1), (1, 0, 1), (-1, 0, 1), (0, 1, 0))
+    back = quad((-1, 0, -1), (-1, 2, -1), (1, 2, -1), (1, 0, -1), (0, 0, 1))
+    panel = quad((-0.3, 1.9, -0.3), (0.3, 1.9, -0.3), (0.3, 1.9, 0.3), (-0.3, 1.9, 0.3), (0, -1, 0))
+    for t in (floor, back):                          # spread the uvs over the whole rect
+        t["uv0"], t["uv1"], t["uv2"] = [[0.05, 0.1], [0.05, 0.1]], [[0.95, 0.1], [0.95, 0.9]], [[0.95, 0.9], [0.05, 0.9]]
+    materials = [
+        {"pbrMetallicRoughness": {"baseColorFactor": [1, 1, 1, 1], "metallicFactor": 1, "roughnessFactor": 1,
+                                  "baseColorTexture": {"index": 0}, "metallicRoughnessTexture": {"index": 2}},
+         "normalTexture": {"index": 1}, "emissiveTexture": {"index": 3}, "emissiveFactor": [0, 0, 0]},
+        {"pbrMetallicRoughness": {"baseColorFactor": [0.9, 0.9, 0.9, 1], "metallicFactor": 0, "roughnessFactor": 0.6,
+                                  "baseColorTexture": {"index": 0}}},
+        {"pbrMetallicRoughness": {"baseColorFactor": [1, 1, 1, 1]}, "emissiveFactor": [1, 1, 1],
+         "extensions": {"KHR_materials_emissive_strength": {"emissiveStrength": 12.0}}},
+        {"pbrMetallicRoughness": {"baseColorTexture": {"index": 3}}},
+    ]
+    nodes = [{"mesh": 0}, {"mesh": 1}, {"mesh": 2}]
+    glb_io.write_glb(str(path), [mesh_of(floor, 0), mesh_of(back, 1), mesh_of(panel, 2)], nodes, materials,
+                     images=[glb_io.encode_png(i) for i in images], textures=[0, 1, 2, 3])
+    refs = [{"albedo": 0, "normal": 1, "pbr": 2, "emissive": 3}, {"albedo": 0}, {}, {"albedo": 3}]
+    return images, refs
+
+
+@pytest.mark.parametrize("sizes", [[(64, 64), (32, 32), (16, 64), (8, 8)],          # even: 2x2 box means
+                                   [(33, 17), (20, 7), (5, 5), (1, 3)]])             # odd: fractional boxes
+def test_atlas_and_material_rects_match_restatement(tmp_path, sizes):
+    _build()
+    rng = np.random.default_rng(len(sizes) + sizes[0][0])
+    glb = tmp_path / "tex.glb"
+    images, refs = _textured_glb(glb, rng, sizes)
+    out = tmp_path / "blobs"
+    out.mkdir()
+    subprocess.check_call([NODE, os.path.join(HOST, "prepare_cli.js"), str(glb), str(out)], stdout=subprocess.DEVNULL)
+    info = json.loads((out / "info.json").read_text())
+    rects, canvas, atlas = atlas_ref.build(refs, images)
+
+    size = info["atlas"]["width"]
+    assert size == info["atlas"]["height"] == canvas.shape[0] and size & (size - 1) == 0
+    got8 = np.fromfile(out / "atlas_rgba8.bin", np.uint8).reshape(size, size, 4)
+    assert np.array_equal(got8, canvas)
+    got16 = np.fromfile(out / "atlas.bin", np.uint16).reshape(size, size, 4)
+    assert np.array_equal(got16, atlas.view(np.uint16))
+    assert got8[..., :3].any() and (got8[..., 3] == 255).all()
+
+    # material blob: one entry per primitive (gpu.ts:285-291), rects stored through Uint32Array (fractions truncate)
+    mats = np.fromfile(out / "materials.bin", layout.MATERIAL)
+    assert len(mats) == 3
+    for m, r in zip(mats, rects[:3]):
+        for field, key in (("albedo_map", "albedo"), ("normal_map", "normal"), ("pbr_map", "pbr"), ("emissive_map", "emissive")):
+            assert [int(v) for v in m[field]] == [int(v) for v in r[key]], (field, r[key])
+    if sizes[0] == (64, 64):
+        # even sizes: every texel of a non-albedo rect is the rounded mean of its 2x2 source block
+        x, y, w, h = (int(v) for v in rects[0]["pbr"])
+        src = images[2].astype(np.float64)
+        mean = (src[0::2, 0::2] + src[1::2, 0::2] + src[0::2, 1::2] + src[1::2, 1::2]) / 4
+        assert np.array_equal(got8[y:y + h, x:x + w, :3], np.floor(mean[..., :3] + 0.5).astype(np.uint8))
+
+
+def test_untextured_scene_gets_a_1x1_black_atlas(tmp_path):
+    _build()
+    import test_gltf_host
+    glb = tmp_path / "plain.glb"
+    test_gltf_host.synthetic_glb(str(glb))
+    out = tmp_path / "blobs"
+    out.mkdir()
+    subprocess.check_call([NODE, os.path.join(HOST, "prepare_cli.js"), str(glb), str(out)], stdout=subprocess.DEVNULL)
+    info = json.loads((out / "info.json").read_text())
+    assert info["atlas"] == {"width": 1, "height": 1, "format": 1}          # atlas.ts:65-68: max(1, 2^ceil(log2(0)))
+    assert np.fromfile(out / "atlas.bin", np.float16).tolist() == [0, 0, 0, 1]
+    mats = np.fromfile(out / "materials.bin", layout.MATERIAL)
+    for field in ("albedo_map", "normal_map", "pbr_map", "emissive_map"):
+        assert not any(mats[field][k].any() for k in "xywh")
+
+
+def test_jpeg_texture_is_rejected_loudly(tmp_path):
+    glb = tmp_path / "jpeg.glb"
+    tri = scenes._quad((-1, 0, -1), (1, 0, -1), (1, 0, 1), (-1, 0, 1), (0, 1, 0), 0)
+    pos = np.stack([tri["v0"], tri["v1"], tri["v2"]], 1).reshape(-1, 3)
+    nrm = np.stack([tri["n0"], tri["n1"], tri["n2"]], 1).reshape(-1, 3)
+    glb_io.write_glb(str(glb), [{"positions": pos, "normals": nrm, "uvs": None, "indices": np.arange(len(pos)), "material": 0}],
+                     [{"mesh": 0}], [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}}],
+                     images=[b"\xff\xd8\xff\xe0" + b"\0" * 32], textures=[0])
+    r = subprocess.run([NODE, os.path.join(HOST, "prepare_cli.js"), str(glb), str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode != 0 and "JPEG" in r.stderr
+
+
+@pytest.mark.gpu
+def test_textured_glb_render_through_node_matches_oracle(tmp_path, oracle):
+    """textured .glb -> JS host (PNG decode, atlas, rects, BVH) -> N-API -> HIP, against the oracle on the blobs and
+    the atlas the host built; the textures must matter (a render without the atlas differs)."""
+    _build()
+    rng = np.random.default_rng(11)
+    glb = tmp_path / "tex.glb"
+    _textured_glb(glb, rng, [(64, 64), (32, 32), (16, 64), (8, 8)])
+    out = tmp_path / "blobs"
+    out.mkdir()
+    subprocess.check_call([NODE, os.path.join(HOST, "prepare_cli.js"), str(glb), str(out)], stdout=subprocess.DEVNULL)
+    sc = glb_io.load_blob_dir(str(out))
+    assert sc.atlas is not None and sc.atlas.shape[0] >= 32
+    W, H, frames = 96, 64, 6
+    cmd = [NODE, os.path.join(HOST, "render_cli.js"), glb, tmp_path / "o.f32", "--width", W, "--height", H,
+           "--frames", frames, "--batch", 3]
+    txt = subprocess.check_output([str(c) for c in cmd], text=True)
+    st = json.loads(txt.strip().splitlines()[-1])
+    got = np.fromfile(tmp_path / "o.f32", np.float32).reshape(H, W, 4)
+    cam = layout.make_camera(W, H)
+    ref, ost = oracle.render(sc, cam, frames)
+    assert st["segments"] == ost.segments and st["shadowRays"] == ost.shadow_rays
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    plain = scenes.Scene("plain", sc.tris, sc.mats, sc.nodes, sc.lights, None)
+    ref_plain, _ = oracle.render(plain, cam, frames)
+    assert not np.array_equal(ref_plain, ref) and got[..., :3].mean() > 0.005

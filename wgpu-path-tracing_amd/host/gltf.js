@@ -4,9 +4,12 @@
  * @loaders.gl/gltf's load + postProcessGLTF (src/renderer/loader.ts:13-17), reduced to the fields
  * src/renderer/gpu.ts reads: nodes (children, matrix | TRS, mesh, light), mesh primitives with
  * POSITION / NORMAL / TEXCOORD_0 / indices as typed arrays, materials, KHR_lights_punctual lights.
- * Images / textures are not decoded (the atlas builder is a later row, SURVEY.md §8f rank 3).
+ * Images are decoded to RGBA8 ({width, height, data}; PNG only — a JPEG texture raises an error) and texture
+ * references are resolved the way postProcessGLTF does (`material.normalTexture.texture.source.image`), which is
+ * what src/renderer/atlas.ts:36-48 walks.
  */
 var fs = require('fs');
+var decodePNG = require('./png_decode').decodePNG;
 
 var COMPONENTS = { 5120: Int8Array, 5121: Uint8Array, 5122: Int16Array, 5123: Uint16Array, 5125: Uint32Array, 5126: Float32Array };
 var COUNTS = { SCALAR: 1, VEC2: 2, VEC3: 3, VEC4: 4, MAT2: 4, MAT3: 9, MAT4: 16 };
@@ -41,11 +44,40 @@ function readAccessor(json, bin, index) {
   return { value: out, size: n };
 }
 
-/** The post-processed shape gpu.ts consumes: index references resolved to objects. */
+/** bytes of image i: a GLB bufferView or a base64 data URI */
+function imageBytes(json, bin, img) {
+  if (img.bufferView !== undefined) {
+    var view = json.bufferViews[img.bufferView];
+    if (view.buffer !== 0 || !bin) throw new Error('only the GLB-embedded buffer is supported');
+    return bin.slice(view.byteOffset || 0, (view.byteOffset || 0) + view.byteLength);
+  }
+  var m = /^data:[^;,]*;base64,(.*)$/.exec(img.uri || '');
+  if (!m) throw new Error('image "' + (img.name || '') + '": external files are not supported');
+  return Buffer.from(m[1], 'base64');
+}
+
+function decodeImage(bytes, name) {
+  if (bytes.length >= 8 && bytes[0] === 137 && bytes[1] === 80) return decodePNG(bytes);
+  if (bytes.length >= 2 && bytes[0] === 0xff && bytes[1] === 0xd8) throw new Error('image "' + name + '": JPEG textures are not supported');
+  throw new Error('image "' + name + '": unknown format');
+}
+
+/** The post-processed shape gpu.ts and atlas.ts consume: index references resolved to objects. */
 function loadGLB(pathOrBuffer) {
   var buf = typeof pathOrBuffer === 'string' ? fs.readFileSync(pathOrBuffer) : pathOrBuffer;
   var glb = parseGLB(buf), json = glb.json, bin = glb.bin;
-  var materials = (json.materials || []).map(function (m) { return m; });
+  var images = (json.images || []).map(function (img, i) {
+    return { name: img.name, mimeType: img.mimeType, image: decodeImage(imageBytes(json, bin, img), img.name || String(i)) };
+  });
+  var textures = (json.textures || []).map(function (t) {
+    return { name: t.name, sampler: t.sampler, source: t.source !== undefined ? images[t.source] : undefined };
+  });
+  var resolve = function (info) { if (info && info.index !== undefined) info.texture = textures[info.index]; };
+  var materials = (json.materials || []).map(function (m) {
+    resolve(m.normalTexture); resolve(m.occlusionTexture); resolve(m.emissiveTexture);
+    if (m.pbrMetallicRoughness) { resolve(m.pbrMetallicRoughness.baseColorTexture); resolve(m.pbrMetallicRoughness.metallicRoughnessTexture); }
+    return m;
+  });
   var rootLights = json.extensions && json.extensions.KHR_lights_punctual ? json.extensions.KHR_lights_punctual.lights : [];
   var meshes = (json.meshes || []).map(function (mesh) {
     return {
@@ -71,7 +103,7 @@ function loadGLB(pathOrBuffer) {
   (json.nodes || []).forEach(function (n, i) {
     if (n.children) nodes[i].children = n.children.map(function (c) { return nodes[c]; });
   });
-  return { nodes: nodes, meshes: meshes, materials: materials, lights: rootLights, json: json };
+  return { nodes: nodes, meshes: meshes, materials: materials, textures: textures, images: images, lights: rootLights, json: json };
 }
 
 module.exports = { parseGLB: parseGLB, readAccessor: readAccessor, loadGLB: loadGLB };

@@ -63,7 +63,7 @@ Renderer.prototype.loadModel = function (model, atlas) {
     var blobs;
     if (typeof model === 'string' && /\.glb$/i.test(model)) {
       var prepared = require('./scene_prep').prepareScene(require('./gltf').loadGLB(model));
-      blobs = prepared.blobs; self.sceneInfo = prepared;
+      blobs = prepared.blobs; atlas = atlas || prepared.atlas; self.sceneInfo = prepared;
     } else if (typeof model === 'string') {
       var f = sceneFile.readSceneFile(model);
       blobs = f.blobs; atlas = atlas || f.atlas;

@@ -30,8 +30,8 @@ function extractNodeMatrix(node) {
 
 var ZERO_RECT = { x: 0, y: 0, w: 0, h: 0 };
 
-/** gpu.ts:356-421 (atlas rects stay empty until the atlas builder exists) */
-function buildMaterial(material) {
+/** gpu.ts:356-421; atlas = Map(material -> {albedoMap, normalMap, pbrMap, emissiveMap}) from atlas.js packing() */
+function buildMaterial(material, atlas) {
   if (!material) {
     return {
       baseColor: [1, 1, 1], emission: [0, 0, 0], emissiveStrength: 0.0, metallic: 0.0, roughness: 0.1, ior: 1.5,
@@ -43,6 +43,7 @@ function buildMaterial(material) {
   var def = function (v, d) { return v === undefined || v === null ? d : v; };
   var baseColor = def(pbr.baseColorFactor, [1, 1, 1, 1]);
   var emissive = def(material.emissiveFactor, [0, 0, 0]);
+  var rects = (atlas && atlas.get(material)) || {};
   return {
     baseColor: [baseColor[0], baseColor[1], baseColor[2]],
     metallic: def(pbr.metallicFactor, 1.0), roughness: def(pbr.roughnessFactor, 1.0),
@@ -50,7 +51,8 @@ function buildMaterial(material) {
     emissiveStrength: def((ext.KHR_materials_emissive_strength || {}).emissiveStrength, 1.0),
     ior: def((ext.KHR_materials_ior || {}).ior, 1.5),
     transmission: def((ext.KHR_materials_transmission || {}).transmissionFactor, 0.0),
-    albedoMap: ZERO_RECT, normalMap: ZERO_RECT, pbrMap: ZERO_RECT, emissiveMap: ZERO_RECT,
+    albedoMap: rects.albedoMap || ZERO_RECT, normalMap: rects.normalMap || ZERO_RECT,
+    pbrMap: rects.pbrMap || ZERO_RECT, emissiveMap: rects.emissiveMap || ZERO_RECT,
   };
 }
 
@@ -74,7 +76,7 @@ function buildTriangles(position, normal, uv, index) {
 }
 
 /** gpu.ts:194-299 */
-function processNode(gltf, node, allTriangles, allMaterials, allLights, world) {
+function processNode(gltf, node, allTriangles, allMaterials, allLights, world, atlas) {
   var normalMat = M.transpose(M.inverse(world));
   if (node.light !== undefined) {
     var light = gltf.lights[node.light];
@@ -99,14 +101,15 @@ function processNode(gltf, node, allTriangles, allMaterials, allLights, world) {
         tn[i] = n[0]; tn[i + 1] = n[1]; tn[i + 2] = n[2];
       }
       var tris = buildTriangles(tp, tn, uv, prim.indices ? prim.indices.value : undefined);
-      allMaterials.push(buildMaterial(prim.material));
+      allMaterials.push(buildMaterial(prim.material, atlas));
       tris.forEach(function (t) { t.materialIndex = allMaterials.length - 1; allTriangles.push(t); });
     });
   }
 }
 
-/** gpu.ts:67-150 -> { blobs, counts, bvhDepth } */
+/** loader.ts:20-40 + gpu.ts:67-150 -> { blobs, atlas, counts, bvhDepth } */
 function prepareScene(gltf) {
+  var packed = require('./atlas').packing(gltf);
   var allTriangles = [], allMaterials = [], allLights = [];
   var parent = new Map();
   gltf.nodes.forEach(function (n) { (n.children || []).forEach(function (c) { parent.set(c, n); }); });
@@ -117,7 +120,7 @@ function prepareScene(gltf) {
     while (parent.has(cur)) { cur = parent.get(cur); M.mul(extractNodeMatrix(cur), w, w); }
     world.set(node, w);
   });
-  gltf.nodes.forEach(function (node) { processNode(gltf, node, allTriangles, allMaterials, allLights, world.get(node)); });
+  gltf.nodes.forEach(function (node) { processNode(gltf, node, allTriangles, allMaterials, allLights, world.get(node), packed.materials); });
 
   var triangles = pack.packTriangles(allTriangles);             // sorted in place by the BVH build
   var materials = pack.packMaterials(allMaterials);
@@ -126,7 +129,7 @@ function prepareScene(gltf) {
   var lights = a.emissiveLights(triangles, materials, pack.packLights(allLights));
   return {
     blobs: { triangles: triangles, materials: materials, bvhNodes: bvh.nodes, lights: lights },
-    atlas: null,
+    atlas: packed.texture,
     counts: { triangles: allTriangles.length, materials: allMaterials.length, bvhNodes: bvh.nodes.byteLength / pack.BVH_NODE_SIZE,
       lights: lights.byteLength / pack.LIGHT_SIZE, punctualLights: allLights.length },
     bvhDepth: bvh.depth,
