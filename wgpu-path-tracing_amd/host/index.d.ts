@@ -53,3 +53,13 @@ export const pack: {
   packCamera(c: CameraCPU, out?: ArrayBuffer): ArrayBuffer; packScene(s: SceneData): SceneBlobs;
 };
 export function readSceneFile(path: string): { blobs: SceneBlobs; atlas: Atlas | null };
+/** atlas.js — src/renderer/atlas.ts (PackedAtlas): the canvas as RGBA8 and as rgba16float texels, rects per material */
+export interface PackedAtlas {
+  texture: { width: number; height: number; rgba8: Uint8Array; data: Uint16Array; format: 1 };
+  materials: Map<object, { albedoMap: AtlasTexture; normalMap: AtlasTexture; pbrMap: AtlasTexture; emissiveMap: AtlasTexture }>;
+}
+export const atlas: {
+  potpack(boxes: { w: number; h: number; x?: number; y?: number }[]): { w: number; h: number; fill: number };
+  packing(gltf: { materials: object[] }): PackedAtlas;
+};
+export function decodePNG(data: Uint8Array): { width: number; height: number; data: Uint8Array };

@@ -187,4 +187,5 @@ function setupRenderer(options) {
   return r.loadModel(options.model).then(function () { if (options.autoStart) r.start(); return r; });
 }
 
-module.exports = { Renderer: Renderer, setupRenderer: setupRenderer, pack: pack, readSceneFile: sceneFile.readSceneFile };
+module.exports = { Renderer: Renderer, setupRenderer: setupRenderer, pack: pack, readSceneFile: sceneFile.readSceneFile,
+  atlas: require('./atlas'), decodePNG: require('./png_decode').decodePNG };
