@@ -246,7 +246,7 @@ TraverseConfig traverse_config(const ptmi_ctx *c, bool closest_hit) {
     const bool node_cache = have && c->bvh_depth + 2 <= 16 &&
                             (size_t)c->sc.n_wnodes * 64 + (size_t)small_stack * 1024 * 4 <= kLdsMax / 2;
     if (c->opt.traversal == PTMI_TRAVERSAL_GLOBAL) cfg.variant = PT_VARIANT_GLOBAL;
-    else if (closest_hit && node_cache && c->opt.traversal == PTMI_TRAVERSAL_AUTO) {
+    else if (closest_hit && node_cache && c->opt.traversal == PTMI_TRAVERSAL_AUTO) {   // any-hit: measured 15 % slower with it
         cfg.variant = PT_VARIANT_LDS_NODES; cfg.stack_entries = small_stack;
     } else cfg.variant = fits ? PT_VARIANT_LDS : PT_VARIANT_GLOBAL;
     return cfg;

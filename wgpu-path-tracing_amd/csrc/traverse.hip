@@ -33,29 +33,37 @@ namespace {
 constexpr int MODE_EXTEND = 0, MODE_SHADOW = 1;
 constexpr int REFILL_AT = 36;          // refill when at most this many of the 64 lanes still hold a ray
 
+// Loads go through address-space-qualified pointers so that the compiler emits ds_read_b128 /
+// global_load_dwordx4 and never a FLAT load: with generic pointers it merged the LDS read of a node
+// with the (rare) global read of the uploaded tree into one flat_load of a selected address.
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) f4v *lds_f4p;
+typedef const __attribute__((address_space(1))) f4v *glb_f4p;
+PT_DEV float4 as_f4(f4v v) { return make_float4(v.x, v.y, v.z, v.w); }
+PT_DEV void load_node(glb_f4p p, float4 &a, float4 &b, float4 &c, float4 &d) {
+    a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]); d = as_f4(p[3]);
+}
+
 struct GlobalMem {
-    const float4 *wn, *tp;
-    PT_DEV void node(uint32_t i, float4 &a, float4 &b, float4 &c, float4 &d) const {
-        const float4 *p = wn + 4u * (size_t)i;
-        a = p[0]; b = p[1]; c = p[2]; d = p[3];
-    }
+    glb_f4p wn, tp;
+    PT_DEV void node(uint32_t i, float4 &a, float4 &b, float4 &c, float4 &d) const { load_node(wn + 4u * (size_t)i, a, b, c, d); }
     PT_DEV void tri(uint32_t i, float4 &a, float4 &b, float4 &c) const {
-        const float4 *p = tp + 3u * (size_t)i;
-        a = p[0]; b = p[1]; c = p[2];
+        glb_f4p p = tp + 3u * (size_t)i;
+        a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]);
     }
 };
 // wide nodes in LDS; triangle images in LDS too (TRIS_IN_LDS) or read through L1/L2 (the node cache:
 // half the LDS, so two workgroups fit a CU)
 template <bool TRIS_IN_LDS>
 struct LdsMem {
-    const float4 *wn, *tp;
+    lds_f4p wn, tl; glb_f4p tg;
     PT_DEV void node(uint32_t i, float4 &a, float4 &b, float4 &c, float4 &d) const {
-        const float4 *p = wn + 4u * i;
-        a = p[0]; b = p[1]; c = p[2]; d = p[3];
+        lds_f4p p = wn + 4u * i;
+        a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]); d = as_f4(p[3]);
     }
     PT_DEV void tri(uint32_t i, float4 &a, float4 &b, float4 &c) const {
-        const float4 *p = TRIS_IN_LDS ? tp + 3u * i : tp + 3u * (size_t)i;
-        a = p[0]; b = p[1]; c = p[2];
+        if (TRIS_IN_LDS) { lds_f4p p = tl + 3u * i; a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]); }
+        else { glb_f4p p = tg + 3u * (size_t)i; a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]); }
     }
 };
 
@@ -225,8 +233,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
         } else if (can_node) {
             float4 a, b, c, r;
             if (use_ref) {
-                const float4 *p = sc.ref_wnodes + 4u * (size_t)cur;
-                a = p[0]; b = p[1]; c = p[2]; r = p[3];
+                load_node((glb_f4p)sc.ref_wnodes + 4u * (size_t)cur, a, b, c, r);
             } else {
                 m.node(cur, a, b, c, r);
             }
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(GBLOCK) void k_trace_global(DevScene sc, IO io, con
     const uint32_t count = *count_ptr;
     const uint32_t gw = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;       // consecutive groups -> different workgroups
     if (gw * 64u >= count) return;
-    GlobalMem m{sc.wnodes, sc.tripos};
+    GlobalMem m{(glb_f4p)sc.wnodes, (glb_f4p)sc.tripos};
     trace_wave<MODE, CULL, STACK>(m, sc, io, count, gw, gridDim.x * (GBLOCK / 64), stk + threadIdx.x, GBLOCK);
 }
 
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(LBLOCK) void k_trace_lds(DevScene sc, IO io, const 
     __syncthreads();
     const uint32_t gw = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;
     if (gw * 64u >= count) return;
-    LdsMem<TRIS_IN_LDS> m{smem, TRIS_IN_LDS ? smem + nw : sc.tripos};
+    LdsMem<TRIS_IN_LDS> m{(lds_f4p)smem, (lds_f4p)(smem + nw), (glb_f4p)sc.tripos};
     uint32_t *stk = reinterpret_cast<uint32_t *>(smem + nw + nt) + threadIdx.x;
     trace_wave<MODE, CULL, STACK>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk, LBLOCK);
 }

@@ -10,7 +10,7 @@ import numpy as np
 from . import layout
 
 _LIB_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib")
-LIB_PATH = os.path.join(_LIB_DIR, "libptmi.so")
+LIB_PATH = os.environ.get("PTMI_LIB") or os.path.join(_LIB_DIR, "libptmi.so")   # PTMI_LIB: A/B another build of the same ABI
 
 TRAVERSAL_AUTO, TRAVERSAL_GLOBAL, TRAVERSAL_LDS = 0, 1, 2
 ATLAS_RGBA16F, ATLAS_RGBA32F = 1, 2
