@@ -31,7 +31,23 @@
 namespace {
 
 constexpr int MODE_EXTEND = 0, MODE_SHADOW = 1;
-constexpr int REFILL_AT = 36;          // refill when at most this many of the 64 lanes still hold a ray
+#ifndef PT_REFILL_AT
+#define PT_REFILL_AT 36
+#endif
+constexpr int REFILL_AT = PT_REFILL_AT;   // refill when at most this many of the 64 lanes still hold a ray
+// One vote (two ballots, the refill and completion tests) costs about half a box-pair step, so a stream keeps
+// running for up to NODE_STEPS steps / LEAF_STEPS leaves while enough of the lanes that started it can go on:
+// it stops when fewer than 1/NODE_KEEP (1/LEAF_KEEP) of them remain. Measured per kernel on Cornell 1080p.
+#ifndef PT_NODE_STEPS
+#define PT_NODE_STEPS 8
+#endif
+#ifndef PT_LEAF_STEPS
+#define PT_LEAF_STEPS 4
+#endif
+#ifndef PT_LEAF_KEEP
+#define PT_LEAF_KEEP 3
+#endif
+constexpr int NODE_STEPS = PT_NODE_STEPS, LEAF_STEPS = PT_LEAF_STEPS, LEAF_KEEP = PT_LEAF_KEEP;
 
 // Loads go through address-space-qualified pointers so that the compiler emits ds_read_b128 /
 // global_load_dwordx4 and never a FLAT load: with generic pointers it merged the LDS read of a node
@@ -39,6 +55,9 @@ constexpr int REFILL_AT = 36;          // refill when at most this many of the 6
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) f4v *lds_f4p;
 typedef const __attribute__((address_space(1))) f4v *glb_f4p;
+PT_DEV uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// the EXEC-masked lane mask of a predicate, straight from the compare (HIP's __ballot goes through a VGPR 0/1 value)
+PT_DEV uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 PT_DEV float4 as_f4(f4v v) { return make_float4(v.x, v.y, v.z, v.w); }
 PT_DEV void load_node(glb_f4p p, float4 &a, float4 &b, float4 &c, float4 &d) {
     a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]); d = as_f4(p[3]);
@@ -153,7 +172,11 @@ template <int MODE, bool CULL, int STACK, class Mem, class IO>
 PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t count, uint32_t gw,
                              uint32_t total_waves, uint32_t *stk, int stride) {
     constexpr bool ANY = MODE == MODE_SHADOW;
+    constexpr int NODE_KEEP = ANY ? 2 : 3;
     const uint32_t lane = threadIdx.x & 63u;
+    // gw (and so end, next) is the same in all 64 lanes; readfirstlane tells the compiler, which then keeps
+    // the queue bookkeeping in SGPRs and turns the refill / exit tests into scalar branches
+    gw = uniform(gw);
     const uint32_t ngroups = (count + 63u) >> 6;
     const uint32_t end = gw < ngroups ? ((ngroups - gw + total_waves - 1u) / total_waves) * 64u : 0u;
     uint32_t next = 0u;
@@ -165,7 +188,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
     Hit best; best.t = __builtin_inff(); best.u = best.v = 0.0f; best.tri = PT_REF_NONE;
 
     for (;;) {
-        uint64_t act = __ballot(active);
+        uint64_t act = ballot(active);
         if (next < end && __popcll(act) <= REFILL_AT) {
             const uint64_t idle = ~act;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
@@ -196,62 +219,81 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                 }
             }
             next += (uint32_t)__popcll(idle);
-            act = __ballot(active);
+            act = ballot(active);
         }
         if (act == 0ull && next >= end) break;
 
         const bool can_node = active & (cur != PT_REF_NONE) & (STACK - sp - lc >= 2);
         const bool can_tri = active & ((tri_i < tri_e) | (lc > 0));
-        const uint64_t bn = __ballot(can_node), bt = __ballot(can_tri);
-        const bool run_tri = __popcll(bt) > __popcll(bn);
+        const uint64_t bn = ballot(can_node), bt = ballot(can_tri);
+        const bool run_tri = (int)__builtin_popcountll(bt) > (int)__builtin_popcountll(bn);
         bool occluded = false;
         if (run_tri) {
-            if (can_tri) {
-                if (tri_i == tri_e) {                               // next filed leaf
-                    lc--;
-                    const uint32_t ref = stk[(STACK - 1 - lc) * stride];
-                    tri_i = ref & PT_LEAF_OFF_MASK;
-                    tri_e = tri_i + ((ref >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) + 1u;
-                }
-                for (uint32_t ti = tri_i; ti < tri_e; ti++) {       // pt.wgsl:272-279
-                    float4 a, b, c;
-                    m.tri(ti, a, b, c);
-                    float u = 0.0f, v = 0.0f;
-                    const float t = tri_test(xyz(a), xyz(b), xyz(c), o, d, u, v);
-                    const bool hit = t > 0.0f;
-                    if (ANY) {
-                        occluded = occluded | (hit & ((tlim < 0.0f) | (t < tlim)));
-                    } else {
-                        const bool better = hit & ((t < best.t) | ((t == best.t) & (ti < best.tri)));
-                        best.t = better ? t : best.t; best.u = better ? u : best.u;
-                        best.v = better ? v : best.v; best.tri = better ? ti : best.tri;
-                        if (CULL) limit = better ? cull_limit(t) : limit;
+            bool ct = can_tri;
+#pragma unroll 1
+            for (int rep = 0; rep < LEAF_STEPS; rep++) {
+                if (ct) {
+                    if (tri_i == tri_e) {                               // next filed leaf
+                        lc--;
+                        const uint32_t ref = stk[(STACK - 1 - lc) * stride];
+                        tri_i = ref & PT_LEAF_OFF_MASK;
+                        tri_e = tri_i + ((ref >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) + 1u;
                     }
+                    for (uint32_t ti = tri_i; ti < tri_e; ti++) {       // pt.wgsl:272-279
+                        float4 a, b, c;
+                        m.tri(ti, a, b, c);
+                        float u = 0.0f, v = 0.0f;
+                        const float t = tri_test(xyz(a), xyz(b), xyz(c), o, d, u, v);
+                        const bool hit = t > 0.0f;
+                        if (ANY) {
+                            occluded = occluded | (hit & ((tlim < 0.0f) | (t < tlim)));
+                        } else {
+                            const bool better = hit & ((t < best.t) | ((t == best.t) & (ti < best.tri)));
+                            best.t = better ? t : best.t; best.u = better ? u : best.u;
+                            best.v = better ? v : best.v; best.tri = better ? ti : best.tri;
+                            if (CULL) limit = better ? cull_limit(t) : limit;
+                        }
+                    }
+                    tri_i = tri_e;
                 }
-                tri_i = tri_e;
+                if (rep + 1 < LEAF_STEPS) {
+                    ct = ct & (lc > 0) & !occluded;
+                    if ((int)__builtin_popcountll(ballot(ct)) * LEAF_KEEP < (int)__builtin_popcountll(bt)) break;
+                }
             }
-        } else if (can_node) {
-            float4 a, b, c, r;
-            if (use_ref) {
-                load_node((glb_f4p)sc.ref_wnodes + 4u * (size_t)cur, a, b, c, r);
-            } else {
-                m.node(cur, a, b, c, r);
+        } else {
+            // NODE_STEPS box-pair steps per vote: the vote and the bookkeeping around it cost about half a step
+            bool cn = can_node;
+#pragma unroll
+            for (int rep = 0; rep < NODE_STEPS; rep++) {
+                if (cn) {
+                    float4 a, b, c, r;
+                    if (use_ref) {
+                        load_node((glb_f4p)sc.ref_wnodes + 4u * (size_t)cur, a, b, c, r);
+                    } else {
+                        m.node(cur, a, b, c, r);
+                    }
+                    float tl, tr;
+                    bool hl = slab(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, tl);
+                    bool hr = slab(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, tr);
+                    if (CULL) { hl = hl & !(tl > limit); hr = hr & !(tr > limit); }
+                    const uint32_t lref = __float_as_uint(r.x), rref = __float_as_uint(r.y);
+                    const bool ll = (lref & PT_REF_LEAF) != 0u, rl = (rref & PT_REF_LEAF) != 0u;
+                    if (hl & ll) { stk[(STACK - 1 - lc) * stride] = lref; lc++; }
+                    if (hr & rl) { stk[(STACK - 1 - lc) * stride] = rref; lc++; }
+                    const bool il = hl & !ll, ir = hr & !rl;
+                    const bool left_first = tl <= tr;
+                    if (il & ir) { stk[sp * stride] = left_first ? rref : lref; sp++; cur = left_first ? lref : rref; }
+                    else if (il) cur = lref;
+                    else if (ir) cur = rref;
+                    else if (sp > 0) { sp--; cur = stk[sp * stride]; }
+                    else cur = PT_REF_NONE;
+                }
+                if (rep + 1 < NODE_STEPS) {
+                    cn = cn & (cur != PT_REF_NONE) & (STACK - sp - lc >= 2);
+                    if ((int)__builtin_popcountll(ballot(cn)) * NODE_KEEP < (int)__builtin_popcountll(bn)) break;
+                }
             }
-            float tl, tr;
-            bool hl = slab(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, tl);
-            bool hr = slab(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, tr);
-            if (CULL) { hl = hl & !(tl > limit); hr = hr & !(tr > limit); }
-            const uint32_t lref = __float_as_uint(r.x), rref = __float_as_uint(r.y);
-            const bool ll = (lref & PT_REF_LEAF) != 0u, rl = (rref & PT_REF_LEAF) != 0u;
-            if (hl & ll) { stk[(STACK - 1 - lc) * stride] = lref; lc++; }
-            if (hr & rl) { stk[(STACK - 1 - lc) * stride] = rref; lc++; }
-            const bool il = hl & !ll, ir = hr & !rl;
-            const bool left_first = tl <= tr;
-            if (il & ir) { stk[sp * stride] = left_first ? rref : lref; sp++; cur = left_first ? lref : rref; }
-            else if (il) cur = lref;
-            else if (ir) cur = rref;
-            else if (sp > 0) { sp--; cur = stk[sp * stride]; }
-            else cur = PT_REF_NONE;
         }
         // hang guard: an active lane that can take neither stream (cannot happen while STACK > tree depth) ends here
         const bool stuck = active & !can_node & !can_tri & ((bn | bt) == 0ull);
