@@ -38,17 +38,17 @@ PT_DEV void camera_ray(const ptmi_camera &cam, uint32_t x, uint32_t y, uint32_t 
     }
 }
 
+// The throughput of pt.wgsl:639 is not stored: `shade` knows it is (1, 1, 1) at bounce 0 and writes T from then on.
 PT_DEV void init_path(DevPaths P, uint32_t p, v3 o, v3 d, uint32_t rng) {
     P.O[p] = make_float4(o.x, o.y, o.z, __uint_as_float(rng));
     P.D[p] = make_float4(d.x, d.y, d.z, 0.0f);
-    P.T[p] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);      // pt.wgsl:639
     P.L[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);      // pt.wgsl:640
 }
 
-// path id = frame_in_batch * band_pixels + (y - y0) * width + x
+// path id = frame_in_batch * band_pixels + (y - y0) * width + x. The bounce-0 queue is the identity and is
+// not materialised: extend / shade / compact take a null queue as "slot i holds path i".
 __global__ __launch_bounds__(BLOCK) void k_raygen(ptmi_camera cam, DevBand band, uint32_t frame0, uint32_t n_frames,
-                                                  DevPaths P, uint32_t *__restrict__ queue,
-                                                  uint32_t *__restrict__ count_out) {
+                                                  DevPaths P, uint32_t *__restrict__ count_out) {
     const uint32_t npix = (band.y1 - band.y0) * band.width;
     const uint32_t total = npix * n_frames;
     if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = total;
@@ -58,7 +58,6 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(ptmi_camera cam, DevBand band,
         v3 o, d; uint32_t rng;
         camera_ray(cam, x, y, frame0 + k, o, d, rng);
         init_path(P, p, o, d, rng);
-        queue[p] = p;
     }
 }
 
@@ -261,8 +260,8 @@ __global__ void k_math(int op, uint32_t n, const float *a, const float *b, const
 }  // namespace
 
 void pt_launch_raygen(hipStream_t s, int blocks, const ptmi_camera &cam, DevBand band, uint32_t frame0,
-                      uint32_t n_frames, DevPaths p, uint32_t *queue, uint32_t *count_out) {
-    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(BLOCK), 0, s, cam, band, frame0, n_frames, p, queue, count_out);
+                      uint32_t n_frames, DevPaths p, uint32_t *count_out) {
+    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(BLOCK), 0, s, cam, band, frame0, n_frames, p, count_out);
 }
 void pt_launch_raygen_list(hipStream_t s, const ptmi_camera &cam, uint32_t n, const uint32_t *xs,
                            const uint32_t *ys, const uint32_t *frames, DevPaths p) {

@@ -63,7 +63,7 @@ struct TraverseConfig {
 
 // ---- launchers (each enqueues on `s`; grids are persistent, sized by the caller) ----
 void pt_launch_raygen(hipStream_t s, int blocks, const ptmi_camera &cam, DevBand band, uint32_t frame0,
-                      uint32_t n_frames, DevPaths p, uint32_t *queue, uint32_t *count_out);
+                      uint32_t n_frames, DevPaths p, uint32_t *count_out);
 void pt_launch_raygen_list(hipStream_t s, const ptmi_camera &cam, uint32_t n, const uint32_t *xs,
                            const uint32_t *ys, const uint32_t *frames, DevPaths p);
 void pt_launch_extend(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, DevPaths p,

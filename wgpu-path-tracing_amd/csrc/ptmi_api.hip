@@ -444,15 +444,16 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
         for (uint32_t f0 = 0; f0 < n_frames; f0 += F) {
             const uint32_t fb = std::min(F, n_frames - f0);
             const uint32_t frame0 = cam->frame_index + f0;
-            pt_launch_raygen(c->stream, blocks, *cam, band, frame0, fb, c->paths, c->queue[0], &c->counts[0]);
+            pt_launch_raygen(c->stream, blocks, *cam, band, frame0, fb, c->paths, &c->counts[0]);
             int cur = 0;
             for (uint32_t b = 0; b < maxb; b++) {
-                { Timed t(c, 1, t2); pt_launch_extend(c->stream, blocks, cfg, c->sc, c->paths, c->queue[cur], &c->counts[b], c->hits); }
-                { Timed t(c, 2, t3); pt_launch_shade(c->stream, blocks, c->sc, c->paths, c->queue[cur], &c->counts[b], c->hits, c->sh,
+                const uint32_t *q = b == 0 ? nullptr : c->queue[cur];      // bounce 0: slot i holds path i
+                { Timed t(c, 1, t2); pt_launch_extend(c->stream, blocks, cfg, c->sc, c->paths, q, &c->counts[b], c->hits); }
+                { Timed t(c, 2, t3); pt_launch_shade(c->stream, blocks, c->sc, c->paths, q, &c->counts[b], c->hits, c->sh,
                                                      c->alive, c->shadowm, ShadeParams{b, maxb, c->opt.do_mis}); }
                 const bool nee = c->opt.do_mis && c->sc.n_lights > 0;
                 const bool last = b + 1 == maxb;
-                pt_launch_compact(c->stream, tiles, c->queue[cur], &c->counts[b], c->alive, nee ? c->shadowm : nullptr,
+                pt_launch_compact(c->stream, tiles, q, &c->counts[b], c->alive, nee ? c->shadowm : nullptr,
                                   c->word_off, c->queue[cur ^ 1], &c->counts[b + 1], c->sq, &c->counts[kShadowCount],
                                   c->d_stats, b, last ? 0 : 1);
                 if (nee) {

@@ -283,10 +283,10 @@ __global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const
             const uint32_t p = queue ? queue[i] : i;
             const float4 h4 = hits[i];
             if (!(h4.x < 0.0f)) {                                            // pt.wgsl:646: miss adds zero
-                const float4 o4 = P.O[p], d4 = P.D[p], t4 = P.T[p];
+                const float4 o4 = P.O[p], d4 = P.D[p];
                 uint32_t rng = __float_as_uint(o4.w);
                 const v3 ro = xyz(o4), rd = xyz(d4);
-                v3 thr = xyz(t4);
+                v3 thr = sp.bounce == 0u ? mk3(1.0f, 1.0f, 1.0f) : xyz(P.T[p]);     // pt.wgsl:639; raygen stores no T
                 const HitInfo hit = make_hitinfo(sc, ro, rd, h4.x, h4.y, h4.z, __float_as_uint(h4.w));
                 if (hit.emission.x > 0.0f || hit.emission.y > 0.0f || hit.emission.z > 0.0f) {   // pt.wgsl:652-658
                     float att = 1.0f / (1.0f + hit.t * hit.t);
