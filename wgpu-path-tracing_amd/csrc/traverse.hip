@@ -55,6 +55,7 @@ constexpr int NODE_STEPS = PT_NODE_STEPS, LEAF_STEPS = PT_LEAF_STEPS, LEAF_KEEP 
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) f4v *lds_f4p;
 typedef const __attribute__((address_space(1))) f4v *glb_f4p;
+typedef __attribute__((address_space(3))) uint32_t *lds_u32p;
 PT_DEV uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // the EXEC-masked lane mask of a predicate, straight from the compare (HIP's __ballot goes through a VGPR 0/1 value)
 PT_DEV uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -182,7 +183,10 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
     uint32_t next = 0u;
     bool active = false, use_ref = false;
     uint32_t slot = 0, cur = PT_REF_NONE, tri_i = 0, tri_e = 0;
-    int sp = 0, lc = 0;                     // node stack grows from entry 0, the leaf list from entry STACK-1
+    // this lane's LDS entries as two pointers: the node stack grows up from `bot` (sp = next free entry), the list
+    // of filed leaves grows down from `top` (lp = next free entry); STACK - used = (lp - sp) / stride + 1 entries free
+    const lds_u32p bot = (lds_u32p)stk, top = bot + (STACK - 1) * stride;
+    lds_u32p sp = bot, lp = top;
     v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), inv = mk3(0, 0, 0);
     float tlim = 0.0f, limit = __builtin_inff();
     Hit best; best.t = __builtin_inff(); best.u = best.v = 0.0f; best.tri = PT_REF_NONE;
@@ -199,7 +203,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                 io.fetch(slot, o, d, tlim);
                 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                 best.t = __builtin_inff(); best.u = best.v = 0.0f; best.tri = PT_REF_NONE;
-                sp = 0; lc = 0; cur = PT_REF_NONE; tri_i = tri_e = 0u;
+                sp = bot; lp = top; cur = PT_REF_NONE; tri_i = tri_e = 0u;
                 limit = (ANY && CULL && !(tlim < 0.0f)) ? cull_limit(tlim) : __builtin_inff();
                 const bool regular = __builtin_isfinite(inv.x) & __builtin_isfinite(inv.y) & __builtin_isfinite(inv.z) &
                                      (inv.x != 0.0f) & (inv.y != 0.0f) & (inv.z != 0.0f);
@@ -223,8 +227,8 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
         }
         if (act == 0ull && next >= end) break;
 
-        const bool can_node = active & (cur != PT_REF_NONE) & (STACK - sp - lc >= 2);
-        const bool can_tri = active & ((tri_i < tri_e) | (lc > 0));
+        const bool can_node = active & (cur != PT_REF_NONE) & (lp - sp >= stride);      // two entries free
+        const bool can_tri = active & ((tri_i < tri_e) | (lp != top));
         const uint64_t bn = ballot(can_node), bt = ballot(can_tri);
         const bool run_tri = (int)__builtin_popcountll(bt) > (int)__builtin_popcountll(bn);
         bool occluded = false;
@@ -234,8 +238,8 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
             for (int rep = 0; rep < LEAF_STEPS; rep++) {
                 if (ct) {
                     if (tri_i == tri_e) {                               // next filed leaf
-                        lc--;
-                        const uint32_t ref = stk[(STACK - 1 - lc) * stride];
+                        lp += stride;
+                        const uint32_t ref = *lp;
                         tri_i = ref & PT_LEAF_OFF_MASK;
                         tri_e = tri_i + ((ref >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) + 1u;
                     }
@@ -257,7 +261,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                     tri_i = tri_e;
                 }
                 if (rep + 1 < LEAF_STEPS) {
-                    ct = ct & (lc > 0) & !occluded;
+                    ct = ct & (lp != top) & !occluded;
                     if ((int)__builtin_popcountll(ballot(ct)) * LEAF_KEEP < (int)__builtin_popcountll(bt)) break;
                 }
             }
@@ -279,26 +283,26 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                     if (CULL) { hl = hl & !(tl > limit); hr = hr & !(tr > limit); }
                     const uint32_t lref = __float_as_uint(r.x), rref = __float_as_uint(r.y);
                     const bool ll = (lref & PT_REF_LEAF) != 0u, rl = (rref & PT_REF_LEAF) != 0u;
-                    if (hl & ll) { stk[(STACK - 1 - lc) * stride] = lref; lc++; }
-                    if (hr & rl) { stk[(STACK - 1 - lc) * stride] = rref; lc++; }
+                    if (hl & ll) { *lp = lref; lp -= stride; }
+                    if (hr & rl) { *lp = rref; lp -= stride; }
                     const bool il = hl & !ll, ir = hr & !rl;
                     const bool left_first = tl <= tr;
-                    if (il & ir) { stk[sp * stride] = left_first ? rref : lref; sp++; cur = left_first ? lref : rref; }
+                    if (il & ir) { *sp = left_first ? rref : lref; sp += stride; cur = left_first ? lref : rref; }
                     else if (il) cur = lref;
                     else if (ir) cur = rref;
-                    else if (sp > 0) { sp--; cur = stk[sp * stride]; }
+                    else if (sp != bot) { sp -= stride; cur = *sp; }
                     else cur = PT_REF_NONE;
                 }
                 if (rep + 1 < NODE_STEPS) {
-                    cn = cn & (cur != PT_REF_NONE) & (STACK - sp - lc >= 2);
+                    cn = cn & (cur != PT_REF_NONE) & (lp - sp >= stride);
                     if ((int)__builtin_popcountll(ballot(cn)) * NODE_KEEP < (int)__builtin_popcountll(bn)) break;
                 }
             }
         }
         // hang guard: an active lane that can take neither stream (cannot happen while STACK > tree depth) ends here
         const bool stuck = active & !can_node & !can_tri & ((bn | bt) == 0ull);
-        const bool done = active & (occluded | stuck | ((cur == PT_REF_NONE) & (lc == 0) & (tri_i == tri_e)));
-        if (done) { io.finish(slot, best, occluded); active = false; cur = PT_REF_NONE; lc = 0; tri_i = tri_e = 0u; }
+        const bool done = active & (occluded | stuck | ((cur == PT_REF_NONE) & (lp == top) & (tri_i == tri_e)));
+        if (done) { io.finish(slot, best, occluded); active = false; cur = PT_REF_NONE; lp = top; tri_i = tri_e = 0u; }
     }
 }
 
