@@ -39,11 +39,12 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 def pipeline_bytes_per_segment(do_mis, mean_len):
     """SURVEY.md §8(d) re-derived for this build's records:
     extend R 32+4 W 16; shade R 4+16+48 (O,D,T) W 48 + masks 0.25; compact R 4 W 4;
-    MIS: shadow record W 48 R 48 + radiance RMW 32; per path: raygen W 64+4, accumulate R 16 + frame RMW 32."""
+    MIS: shadow record W 48 R 48 + radiance RMW 32; per path: raygen W 48 (O, D, L), accumulate R 16 + frame RMW 32,
+    less what bounce 0 does not touch (the identity queue, 3 x 4, and the stored throughput, 16)."""
     seg = (32 + 4 + 16) + (4 + 16 + 48 + 48) + 8
     if do_mis:
         seg += 48 + 48 + 32
-    return seg + (68 + 48) / max(mean_len, 1e-9)
+    return seg + (48 + 48 - 12 - 16) / max(mean_len, 1e-9)
 
 
 def pmc_traffic(default_workload):
