@@ -65,7 +65,9 @@ typedef struct ptmi_options {
 typedef struct ptmi_stats {
     uint64_t paths;             /* (pixel, frame) samples traced since the last reset */
     uint64_t segments;          /* path segments = bounce-loop iterations reaching sceneIntersect (pt.wgsl:643-644) */
-    uint64_t shadow_rays;       /* shadow traversals (pt.wgsl:392/421/463) */
+    uint64_t shadow_rays;       /* shadow traversals of the reference (pt.wgsl:392/421/463). Those whose contribution is
+                                   exactly zero (light behind the surface) are counted here but not traced: they cannot
+                                   change the radiance */
     uint64_t dispatches;        /* ptmi_dispatch calls */
     uint64_t frames;            /* frames traced */
     uint64_t segments_by_bounce[64];

@@ -50,6 +50,7 @@ struct DevBand { uint32_t width, height, y0, y1; };      // rows [y0,y1) of a wi
 
 struct ShadeParams {
     uint32_t bounce, max_bounces, do_mis;
+    unsigned long long *stats;          // [1] += next-event samples counted but not traced (zero contribution)
 };
 
 enum { PT_VARIANT_GLOBAL = 1, PT_VARIANT_LDS = 2, PT_VARIANT_LDS_NODES = 3 };

@@ -450,7 +450,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
                 const uint32_t *q = b == 0 ? nullptr : c->queue[cur];      // bounce 0: slot i holds path i
                 { Timed t(c, 1, t2); pt_launch_extend(c->stream, blocks, cfg, c->sc, c->paths, q, &c->counts[b], c->hits); }
                 { Timed t(c, 2, t3); pt_launch_shade(c->stream, blocks, c->sc, c->paths, q, &c->counts[b], c->hits, c->sh,
-                                                     c->alive, c->shadowm, ShadeParams{b, maxb, c->opt.do_mis}); }
+                                                     c->alive, c->shadowm, ShadeParams{b, maxb, c->opt.do_mis, c->d_stats}); }
                 const bool nee = c->opt.do_mis && c->sc.n_lights > 0;
                 const bool last = b + 1 == maxb;
                 pt_launch_compact(c->stream, tiles, q, &c->counts[b], c->alive, nee ? c->shadowm : nullptr,

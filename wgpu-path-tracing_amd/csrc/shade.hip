@@ -276,9 +276,10 @@ __global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const
                                                   uint64_t *__restrict__ alive_mask,
                                                   uint64_t *__restrict__ shadow_mask, ShadeParams sp) {
     const uint32_t count = *count_ptr;
+    uint32_t n_skipped = 0;                 // lane 0 of each wave: one atomic per wave at the end
     for (uint32_t base = blockIdx.x * SBLOCK; base < count; base += gridDim.x * SBLOCK) {
         const uint32_t i = base + threadIdx.x;
-        bool alive = false, shadow = false;
+        bool alive = false, shadow = false, skipped = false;
         if (i < count) {
             const uint32_t p = queue ? queue[i] : i;
             const float4 h4 = hits[i];
@@ -304,11 +305,18 @@ __global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const
                             v3 direct = vdiv3(scale3(mul3(ls.intensity, mk3(ev.x, ev.y, ev.z)), wmis),
                                               max1(ls.pdf, PT_EPS));          // pt.wgsl:674
                             v3 contrib = mul3(thr, direct);                   // pt.wgsl:675, added by `shadow`
-                            v3 so = madd3(ls.wi, PT_EPS, hit.position);
-                            S.SO[i] = make_float4(so.x, so.y, so.z, ls.dist);
-                            S.SD[i] = make_float4(ls.wi.x, ls.wi.y, ls.wi.z, __uint_as_float(p));
-                            S.SC[i] = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
-                            shadow = true;
+                            // A contribution of exactly zero (the light is behind the surface: NdotL = 0) leaves the
+                            // radiance unchanged whatever the shadow ray finds (x + 0 = x), so that ray is counted
+                            // in the statistics like the reference's traversal but neither recorded nor traced.
+                            if ((contrib.x != 0.0f) | (contrib.y != 0.0f) | (contrib.z != 0.0f)) {
+                                v3 so = madd3(ls.wi, PT_EPS, hit.position);
+                                S.SO[i] = make_float4(so.x, so.y, so.z, ls.dist);
+                                S.SD[i] = make_float4(ls.wi.x, ls.wi.y, ls.wi.z, __uint_as_float(p));
+                                S.SC[i] = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
+                                shadow = true;
+                            } else {
+                                skipped = true;
+                            }
                         }
                     }
                     v3 dir = sample_bsdf(rng, hit, rd, hit.is_front);         // pt.wgsl:680
@@ -332,12 +340,14 @@ __global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const
                 }
             }
         }
-        const uint64_t am = __ballot(alive), sm = __ballot(shadow);
+        const uint64_t am = __ballot(alive), sm = __ballot(shadow), zm = __ballot(skipped);
         if ((threadIdx.x & 63u) == 0u && i < count) {
             alive_mask[i >> 6] = am;
             shadow_mask[i >> 6] = sm;
+            n_skipped += (uint32_t)__popcll(zm);
         }
     }
+    if (n_skipped) atomicAdd(&sp.stats[1], (unsigned long long)n_skipped);
 }
 
 }  // namespace

@@ -59,6 +59,12 @@ typedef __attribute__((address_space(3))) uint32_t *lds_u32p;
 PT_DEV uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // the EXEC-masked lane mask of a predicate, straight from the compare (HIP's __ballot goes through a VGPR 0/1 value)
 PT_DEV uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// 32-bit forms of two tests the compiler otherwise does in 64 bits (on the VALU): a mask's popcount as an int,
+// and "at least two free entries between the node stack and the leaf list" (a negative difference means none)
+PT_DEV int popc(uint64_t m) { return __builtin_popcount((uint32_t)m) + __builtin_popcount((uint32_t)(m >> 32)); }
+PT_DEV bool room2(lds_u32p lp, lds_u32p sp, int stride) {
+    return (int)((uint32_t)(uintptr_t)lp - (uint32_t)(uintptr_t)sp) >= stride * 4;
+}
 PT_DEV float4 as_f4(f4v v) { return make_float4(v.x, v.y, v.z, v.w); }
 PT_DEV void load_node(glb_f4p p, float4 &a, float4 &b, float4 &c, float4 &d) {
     a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]); d = as_f4(p[3]);
@@ -193,7 +199,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
 
     for (;;) {
         uint64_t act = ballot(active);
-        if (next < end && __popcll(act) <= REFILL_AT) {
+        if (next < end && popc(act) <= REFILL_AT) {
             const uint64_t idle = ~act;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             const uint32_t vi = next + rank;
@@ -227,10 +233,10 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
         }
         if (act == 0ull && next >= end) break;
 
-        const bool can_node = active & (cur != PT_REF_NONE) & (lp - sp >= stride);      // two entries free
+        const bool can_node = active & (cur != PT_REF_NONE) & room2(lp, sp, stride);      // two entries free
         const bool can_tri = active & ((tri_i < tri_e) | (lp != top));
         const uint64_t bn = ballot(can_node), bt = ballot(can_tri);
-        const bool run_tri = (int)__builtin_popcountll(bt) > (int)__builtin_popcountll(bn);
+        const bool run_tri = popc(bt) > popc(bn);
         bool occluded = false;
         if (run_tri) {
             bool ct = can_tri;
@@ -262,7 +268,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                 }
                 if (rep + 1 < LEAF_STEPS) {
                     ct = ct & (lp != top) & !occluded;
-                    if ((int)__builtin_popcountll(ballot(ct)) * LEAF_KEEP < (int)__builtin_popcountll(bt)) break;
+                    if (popc(ballot(ct)) * LEAF_KEEP < popc(bt)) break;
                 }
             }
         } else {
@@ -294,8 +300,8 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                     else cur = PT_REF_NONE;
                 }
                 if (rep + 1 < NODE_STEPS) {
-                    cn = cn & (cur != PT_REF_NONE) & (lp - sp >= stride);
-                    if ((int)__builtin_popcountll(ballot(cn)) * NODE_KEEP < (int)__builtin_popcountll(bn)) break;
+                    cn = cn & (cur != PT_REF_NONE) & room2(lp, sp, stride);
+                    if (popc(ballot(cn)) * NODE_KEEP < popc(bn)) break;
                 }
             }
         }
