@@ -37,6 +37,11 @@ int ptmi_scene_build_bvh(ptmi_triangle *tris, uint32_t n_tris, uint32_t max_leaf
                          ptmi_bvh_node *nodes_out, uint32_t nodes_cap, uint32_t *n_nodes_out,
                          uint32_t *max_depth_out);
 
+/* Threads ptmi_scene_build_bvh may use: 1 = the reference's single loop, 0 (default) = one per hardware thread, at
+ * most 32. Subtrees over disjoint triangle ranges are built concurrently and spliced in the reference's node
+ * order: the output is byte-identical for every thread count. */
+void ptmi_scene_set_threads(int n_threads);
+
 /* gpu.ts:121-138: one emissive light per triangle whose material has
  * length(emission) > 0, in ascending post-sort triangle index, appended after
  * lights_io[0 .. *n_lights_io). */

@@ -150,3 +150,17 @@ def test_builder_rejects_non_finite():
     t["v1"][3, 1] = np.nan
     with pytest.raises(scene_host.SceneError):
         scene_host.build_bvh(t)
+
+
+@pytest.mark.parametrize("n,seed,grid", [(70_000, 11, False), (90_001, 12, True)])
+def test_threaded_builder_is_byte_identical(n, seed, grid):
+    """Ranges above 32 768 triangles are built by several threads and spliced in the reference's node order
+    (left, right, everything under right, everything under left): same bytes as the reference's single loop."""
+    base = _soup(n, seed, grid)
+    one = base.copy()
+    nodes1, depth1 = scene_host.build_bvh(one, threads=1)
+    for threads in (0, 2, 5):
+        many = base.copy()
+        nodes, depth = scene_host.build_bvh(many, threads=threads)
+        assert many.tobytes() == one.tobytes() and nodes.tobytes() == nodes1.tobytes() and depth == depth1
+    assert _check_tree(nodes1, one) == depth1

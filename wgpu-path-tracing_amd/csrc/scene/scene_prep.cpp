@@ -13,7 +13,9 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -137,6 +139,138 @@ void put_node(ptmi_bvh_node &n, const Box &b, uint32_t off, uint32_t cnt) {
     n.triangle_offset = off; n.triangle_count = cnt;
 }
 
+
+// One node of bvh.ts:96-131: sort the range along the longest axis and pick the cheapest of the `bins - 1`
+// equal-count candidates. Returns the split position, or `start` when no candidate has a finite cost.
+struct SplitScratch { std::vector<Keyed> keys; std::vector<ptmi_triangle> tmp; std::vector<uint32_t> cand; std::vector<Box> lbox, rbox; };
+
+uint32_t choose_split(ptmi_triangle *tris, uint32_t start, uint32_t end, uint32_t bins, SplitScratch &w) {
+    const uint32_t num = end - start;
+    int axis = range_box(tris, start, end).max_axis();                                  // bvh.ts:96-97
+    // bvh.ts:100-102, :160-168: sort the range by (v0+v1+v2)[axis] / 3
+    w.keys.resize(num);
+    for (uint32_t i = 0; i < num; i++) {
+        const ptmi_triangle &q = tris[start + i];
+        w.keys[i].key = ((double)q.v0[axis] + (double)q.v1[axis] + (double)q.v2[axis]) / 3.0;
+        w.keys[i].idx = start + i;
+    }
+    PartialSorter<Keyed, CmpKeyed> sorter{w.keys.data(), CmpKeyed()};
+    sorter.run(0, (int64_t)num);
+    w.tmp.resize(num);
+    for (uint32_t i = 0; i < num; i++) w.tmp[i] = tris[w.keys[i].idx];
+    std::memcpy(tris + start, w.tmp.data(), (size_t)num * sizeof(ptmi_triangle));
+
+    // bvh.ts:171-199: candidates at start + floor(num * i/bins); left/right boxes from one forward and one
+    // backward sweep (min/max are exact, so the boxes equal the reference's per-candidate recomputation)
+    w.cand.clear();
+    for (uint32_t i = 1; i < bins; i++) {
+        double ratio = (double)i / (double)bins;
+        uint32_t split = start + (uint32_t)std::floor((double)num * ratio);
+        if (split == start || split == end) continue;
+        w.cand.push_back(split);
+    }
+    w.lbox.resize(w.cand.size()); w.rbox.resize(w.cand.size());
+    {
+        Box b; b.reset(); uint32_t pos = start;
+        for (size_t c = 0; c < w.cand.size(); c++) {
+            for (; pos < w.cand[c]; pos++) b.grow(tris[pos]);
+            w.lbox[c] = b;
+        }
+        b.reset(); pos = end;
+        for (size_t c = w.cand.size(); c-- > 0;) {
+            for (; pos > w.cand[c]; pos--) b.grow(tris[pos - 1]);
+            w.rbox[c] = b;
+        }
+    }
+    double min_cost = std::numeric_limits<double>::infinity();
+    uint32_t best = start;
+    for (size_t c = 0; c < w.cand.size(); c++) {
+        double lc = w.lbox[c].area() * (double)(w.cand[c] - start);
+        double rc = w.rbox[c].area() * (double)(end - w.cand[c]);
+        double cost = 1.0 + (lc + rc) * 2.0;                                            // bvh.ts:206-229
+        if (cost < min_cost) { min_cost = cost; best = w.cand[c]; }
+    }
+    return best;
+}
+
+// ---- the same tree from several threads ------------------------------------------------------------------
+// The reference's explicit stack (bvh.ts:74-152) pops the right child first, so the nodes below a split are
+// numbered: left, right, then everything under right, then everything under left. Disjoint triangle ranges are
+// independent, so the two sides can be built concurrently into their own arrays (links relative to the array)
+// and spliced in that order; the result is byte-identical to the one-thread loop.
+constexpr uint32_t kParallelMin = 1u << 15;      // ranges below this are built by the calling thread
+std::atomic<int> g_threads{0};                    // 0 = one per hardware thread (at most 32)
+
+struct Subtree {
+    std::vector<ptmi_bvh_node> below;             // all nodes under the range's own node, in the reference's order
+    uint32_t depth = 0;                           // deepest leaf, counted from the root = 1
+    bool failed = false;
+};
+
+void rebase(std::vector<ptmi_bvh_node> &v, uint32_t by) {
+    for (ptmi_bvh_node &n : v)
+        if (n.triangle_count == 0) { n.left += by; n.right += by; }
+}
+
+void build_below(ptmi_triangle *tris, uint32_t start, uint32_t end, uint32_t depth, uint32_t max_leaf, uint32_t bins,
+                 std::atomic<int> &spare, Subtree &out) {
+    if (end - start <= kParallelMin) {
+        // the reference's loop, numbering relative to out.below
+        struct Task { int64_t node; uint32_t start, end, depth; };   // node -1 = the range's own node (not in `below`)
+        SplitScratch w;
+        std::vector<Task> work;
+        work.push_back({-1, start, end, depth});
+        while (!work.empty()) {
+            Task t = work.back(); work.pop_back();
+            if (t.depth > out.depth) out.depth = t.depth;
+            if (t.end - t.start <= max_leaf) continue;                // leaves keep what put_node wrote
+            uint32_t best = choose_split(tris, t.start, t.end, bins, w);
+            if (best == t.start) { out.failed = true; return; }
+            uint32_t li = (uint32_t)out.below.size(), ri = li + 1;
+            out.below.resize(out.below.size() + 2);
+            put_node(out.below[li], range_box(tris, t.start, best), t.start, best - t.start);
+            put_node(out.below[ri], range_box(tris, best, t.end), best, t.end - best);
+            if (t.node >= 0) {
+                ptmi_bvh_node &p = out.below[(size_t)t.node];
+                p.left = li; p.right = ri; p.triangle_count = 0; p.triangle_offset = 0;
+            }
+            work.push_back({(int64_t)li, t.start, best, t.depth + 1});
+            work.push_back({(int64_t)ri, best, t.end, t.depth + 1});
+        }
+        return;
+    }
+    if (depth > out.depth) out.depth = depth;
+    SplitScratch w;
+    uint32_t best = choose_split(tris, start, end, bins, w);
+    if (best == start) { out.failed = true; return; }
+    w = SplitScratch();
+    Subtree L, R;
+    bool spawned = false;
+    std::thread th;
+    int have = spare.load();
+    while (have > 0 && !spare.compare_exchange_weak(have, have - 1)) {}
+    if (have > 0) {
+        spawned = true;
+        th = std::thread([&] { build_below(tris, best, end, depth + 1, max_leaf, bins, spare, R); });
+    } else {
+        build_below(tris, best, end, depth + 1, max_leaf, bins, spare, R);
+    }
+    build_below(tris, start, best, depth + 1, max_leaf, bins, spare, L);
+    if (spawned) { th.join(); spare.fetch_add(1); }
+    if (L.failed || R.failed) { out.failed = true; return; }
+    // below = [left, right] + below(right) + below(left); a side's own children are the first two of its array
+    out.below.resize(2);
+    put_node(out.below[0], range_box(tris, start, best), start, best - start);
+    put_node(out.below[1], range_box(tris, best, end), best, end - best);
+    const uint32_t r_at = 2, l_at = 2 + (uint32_t)R.below.size();
+    if (!R.below.empty()) { out.below[1].left = r_at; out.below[1].right = r_at + 1; out.below[1].triangle_count = 0; out.below[1].triangle_offset = 0; }
+    if (!L.below.empty()) { out.below[0].left = l_at; out.below[0].right = l_at + 1; out.below[0].triangle_count = 0; out.below[0].triangle_offset = 0; }
+    rebase(R.below, r_at); rebase(L.below, l_at);
+    out.below.insert(out.below.end(), R.below.begin(), R.below.end());
+    out.below.insert(out.below.end(), L.below.begin(), L.below.end());
+    out.depth = std::max(out.depth, std::max(L.depth, R.depth));
+}
+
 }  // namespace
 
 extern "C" {
@@ -157,6 +291,8 @@ int ptmi_scene_sort_partially_f64(double *arr, int64_t n, int64_t start, int64_t
 
 uint32_t ptmi_scene_bvh_node_bound(uint32_t n_tris) { return n_tris ? 2u * n_tris - 1u : 1u; }
 
+void ptmi_scene_set_threads(int n_threads) { g_threads.store(n_threads); }
+
 int ptmi_scene_build_bvh(ptmi_triangle *tris, uint32_t n, uint32_t max_leaf, uint32_t bins,
                          ptmi_bvh_node *out, uint32_t cap, uint32_t *n_nodes_out,
                          uint32_t *max_depth_out) {
@@ -170,9 +306,25 @@ int ptmi_scene_build_bvh(ptmi_triangle *tris, uint32_t n, uint32_t max_leaf, uin
                 return fail(-4, "non-finite vertex position (the reference's builder does not terminate on it)");
 
     struct Task { uint32_t node, start, end, depth; };
+    int threads = g_threads.load();
+    if (threads <= 0) { threads = (int)std::thread::hardware_concurrency(); if (threads > 32) threads = 32; }
+    if (threads > 1 && n > kParallelMin) {
+        std::atomic<int> spare{threads - 1};
+        Subtree sub;
+        build_below(tris, 0, n, 1, max_leaf, bins, spare, sub);
+        if (sub.failed) return fail(-5, "no finite SAH split (the reference's builder does not terminate here)");
+        if (sub.below.size() + 1 > cap) return fail(-3, "node capacity too small");
+        put_node(out[0], range_box(tris, 0, n), 0, n);                                  // bvh.ts:63-71
+        if (!sub.below.empty()) { out[0].left = 1; out[0].right = 2; out[0].triangle_count = 0; out[0].triangle_offset = 0; }
+        rebase(sub.below, 1);
+        std::memcpy(out + 1, sub.below.data(), sub.below.size() * sizeof(ptmi_bvh_node));
+        *n_nodes_out = (uint32_t)sub.below.size() + 1;
+        if (max_depth_out) *max_depth_out = sub.depth;
+        return 0;
+    }
+
     std::vector<Task> work;
-    std::vector<Keyed> keys;
-    std::vector<ptmi_triangle> tmp;
+    SplitScratch scratch;
     uint32_t count = 0, max_depth = 0;
 
     put_node(out[count++], range_box(tris, 0, n), 0, n);                                // bvh.ts:63-71
@@ -187,51 +339,7 @@ int ptmi_scene_build_bvh(ptmi_triangle *tris, uint32_t n, uint32_t max_leaf, uin
             out[t.node].triangle_count = num;
             continue;
         }
-        int axis = range_box(tris, t.start, t.end).max_axis();                          // bvh.ts:96-97
-        // bvh.ts:100-102, :160-168: sort the range by (v0+v1+v2)[axis] / 3
-        keys.resize(num);
-        for (uint32_t i = 0; i < num; i++) {
-            const ptmi_triangle &q = tris[t.start + i];
-            keys[i].key = ((double)q.v0[axis] + (double)q.v1[axis] + (double)q.v2[axis]) / 3.0;
-            keys[i].idx = t.start + i;
-        }
-        PartialSorter<Keyed, CmpKeyed> sorter{keys.data(), CmpKeyed()};
-        sorter.run(0, (int64_t)num);
-        tmp.resize(num);
-        for (uint32_t i = 0; i < num; i++) tmp[i] = tris[keys[i].idx];
-        std::memcpy(tris + t.start, tmp.data(), (size_t)num * sizeof(ptmi_triangle));
-
-        // bvh.ts:171-199: candidates at start + floor(num * i/bins); left/right
-        // boxes from one forward and one backward sweep (min/max are exact, so
-        // the boxes equal the reference's per-candidate recomputation)
-        std::vector<uint32_t> cand;
-        for (uint32_t i = 1; i < bins; i++) {
-            double ratio = (double)i / (double)bins;
-            uint32_t split = t.start + (uint32_t)std::floor((double)num * ratio);
-            if (split == t.start || split == t.end) continue;
-            cand.push_back(split);
-        }
-        std::vector<Box> lbox(cand.size()), rbox(cand.size());
-        {
-            Box b; b.reset(); uint32_t pos = t.start;
-            for (size_t c = 0; c < cand.size(); c++) {
-                for (; pos < cand[c]; pos++) b.grow(tris[pos]);
-                lbox[c] = b;
-            }
-            b.reset(); pos = t.end;
-            for (size_t c = cand.size(); c-- > 0;) {
-                for (; pos > cand[c]; pos--) b.grow(tris[pos - 1]);
-                rbox[c] = b;
-            }
-        }
-        double min_cost = std::numeric_limits<double>::infinity();
-        uint32_t best = t.start;
-        for (size_t c = 0; c < cand.size(); c++) {
-            double lc = lbox[c].area() * (double)(cand[c] - t.start);
-            double rc = rbox[c].area() * (double)(t.end - cand[c]);
-            double cost = 1.0 + (lc + rc) * 2.0;                                        // bvh.ts:206-229
-            if (cost < min_cost) { min_cost = cost; best = cand[c]; }
-        }
+        uint32_t best = choose_split(tris, t.start, t.end, bins, scratch);
         if (best == t.start)
             return fail(-5, "no finite SAH split (the reference's builder does not terminate here)");
         if (count + 2 > cap) return fail(-3, "node capacity too small");

@@ -31,6 +31,8 @@ def lib():
                                                     ctypes.c_int64, ctypes.c_int]
         L.ptmi_scene_build_bvh.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                            ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+        L.ptmi_scene_set_threads.argtypes = [ctypes.c_int]
+        L.ptmi_scene_set_threads.restype = None
         L.ptmi_scene_emissive_lights.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32,
                                                  ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
         _lib = L
@@ -49,10 +51,12 @@ def sort_partially(arr, start, end, descending=False):
     return a
 
 
-def build_bvh(tris, max_leaf=4, bins=12):
-    """Sorts `tris` (TRIANGLE array) in place and returns (nodes, max_depth)."""
+def build_bvh(tris, max_leaf=4, bins=12, threads=0):
+    """Sorts `tris` (TRIANGLE array) in place and returns (nodes, max_depth). threads: 1 = the reference's single
+    loop, 0 = one per hardware thread; the result is byte-identical either way."""
     assert tris.dtype == layout.TRIANGLE and tris.flags.c_contiguous
     L = lib()
+    L.ptmi_scene_set_threads(int(threads))
     cap = L.ptmi_scene_bvh_node_bound(len(tris))
     nodes = np.zeros(cap, layout.BVH_NODE)
     n = ctypes.c_uint32(0)
