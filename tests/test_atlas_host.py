@@ -224,16 +224,83 @@ def test_untextured_scene_gets_a_1x1_black_atlas(tmp_path):
         assert not any(mats[field][k].any() for k in "xywh")
 
 
-def test_jpeg_texture_is_rejected_loudly(tmp_path):
-    glb = tmp_path / "jpeg.glb"
+def _quad_glb(path, image_bytes):
     tri = scenes._quad((-1, 0, -1), (1, 0, -1), (1, 0, 1), (-1, 0, 1), (0, 1, 0), 0)
     pos = np.stack([tri["v0"], tri["v1"], tri["v2"]], 1).reshape(-1, 3)
     nrm = np.stack([tri["n0"], tri["n1"], tri["n2"]], 1).reshape(-1, 3)
-    glb_io.write_glb(str(glb), [{"positions": pos, "normals": nrm, "uvs": None, "indices": np.arange(len(pos)), "material": 0}],
+    glb_io.write_glb(str(path), [{"positions": pos, "normals": nrm, "uvs": None, "indices": np.arange(len(pos)), "material": 0}],
                      [{"mesh": 0}], [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}}],
-                     images=[b"\xff\xd8\xff\xe0" + b"\0" * 32], textures=[0])
+                     images=[image_bytes], textures=[0])
+
+
+def test_broken_jpeg_texture_is_rejected_loudly(tmp_path):
+    glb = tmp_path / "jpeg.glb"
+    _quad_glb(glb, b"\xff\xd8\xff\xe0" + b"\0" * 32)
     r = subprocess.run([NODE, os.path.join(HOST, "prepare_cli.js"), str(glb), str(tmp_path)], capture_output=True, text=True)
     assert r.returncode != 0 and "JPEG" in r.stderr
+
+
+JPEG_DECODE = """
+var fs = require('fs'), d = require('./jpeg_decode').decodeJPEG(fs.readFileSync(process.argv[1]));
+fs.writeFileSync(process.argv[2], Buffer.from(d.data.buffer, d.data.byteOffset, d.data.byteLength));
+console.log(d.width + ' ' + d.height);
+"""
+
+
+def _smooth(rng, h, w, ch=3):
+    a = rng.random((h // 4 + 2, w // 4 + 2, ch))
+    return (np.kron(a, np.ones((4, 4, 1)))[:h, :w] * 255).astype(np.uint8)
+
+
+def test_jpeg_decoder_matches_libjpeg_turbo_bit_for_bit(tmp_path):
+    """Browsers decode glTF's JPEG textures with libjpeg-turbo's defaults (integer "islow" IDCT, fancy upsampling);
+    Pillow links the same library, so it pins host/jpeg_decode.js: sequential and progressive files, optimised
+    Huffman tables, 4:4:4 / 4:2:2 / 4:2:0, odd sizes down to 1x1, grey, restart intervals."""
+    Image = pytest.importorskip("PIL.Image")
+    import io
+    rng = np.random.default_rng(5)
+    cases = []
+    for (h, w) in [(16, 16), (17, 23), (1, 1), (2, 2), (33, 5), (3, 40), (64, 48)]:
+        for ss in (0, 1, 2):
+            for prog in (False, True):
+                cases.append((_smooth(rng, h, w), dict(quality=int(rng.choice([30, 75, 92])), subsampling=ss, progressive=prog,
+                                                       optimize=bool(rng.integers(2)))))
+    cases.append((_smooth(rng, 37, 29, 1)[..., 0], dict(quality=80)))
+    cases.append((_smooth(rng, 37, 29, 1)[..., 0], dict(quality=80, progressive=True)))
+    cases.append((_smooth(rng, 50, 70), dict(quality=85, subsampling=2, restart_marker_blocks=3)))
+    cases.append((_smooth(rng, 50, 70), dict(quality=85, subsampling=0, restart_marker_rows=1, progressive=True)))
+    for k, (img, opts) in enumerate(cases):
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, "JPEG", **opts)
+        want = np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB"))
+        src, dst = tmp_path / ("c%d.jpg" % k), tmp_path / ("c%d.rgba" % k)
+        src.write_bytes(buf.getvalue())
+        w, h = map(int, node(JPEG_DECODE, src, dst).split())
+        got = np.fromfile(dst, np.uint8).reshape(h, w, 4)
+        assert (h, w) == want.shape[:2] and (got[..., 3] == 255).all()
+        assert np.array_equal(got[..., :3], want), (k, img.shape, opts)
+
+
+def test_jpeg_texture_reaches_the_atlas(tmp_path):
+    Image = pytest.importorskip("PIL.Image")
+    import io
+    _build()
+    rng = np.random.default_rng(6)
+    img = _smooth(rng, 32, 48)
+    buf = io.BytesIO()
+    Image.fromarray(img).save(buf, "JPEG", quality=90)
+    decoded = np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB"))
+    glb = tmp_path / "j.glb"
+    _quad_glb(glb, buf.getvalue())
+    out = tmp_path / "blobs"
+    out.mkdir()
+    subprocess.check_call([NODE, os.path.join(HOST, "prepare_cli.js"), str(glb), str(out)], stdout=subprocess.DEVNULL)
+    info = json.loads((out / "info.json").read_text())
+    size = info["atlas"]["width"]
+    rgba = np.concatenate([decoded, np.full(decoded.shape[:2] + (1,), 255, np.uint8)], 2)
+    rects, canvas, _ = atlas_ref.build([{"albedo": 0}], [rgba])
+    assert size == canvas.shape[0] == 32
+    assert np.array_equal(np.fromfile(out / "atlas_rgba8.bin", np.uint8).reshape(size, size, 4), canvas)
 
 
 @pytest.mark.gpu

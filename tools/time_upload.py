@@ -1,0 +1,13 @@
+#!/usr/bin/env python3
+"""Times ptmi_upload_scene (validation + traversal-image build + copies) per scene on the GPU box."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "wgpu-path-tracing_amd"))
+from ptmi import native, scenes
+ctx = native.Context(0)
+for name in sys.argv[1:] or ["cornell", "cornell_spheres", "grid_1m"]:
+    t = time.time(); sc = scenes.make(name); t_make = time.time() - t
+    for keep in (0, 1):
+        ctx.set_options(keep_reference_tree=keep)
+        t = time.time(); ctx.upload_scene(sc); dt = time.time() - t
+        print(f"{name:16s} triangles {len(sc.tris):8d} host prep {t_make:6.2f} s  upload(keep_reference_tree={keep}) {dt:6.3f} s", flush=True)

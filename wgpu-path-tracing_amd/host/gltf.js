@@ -4,12 +4,13 @@
  * @loaders.gl/gltf's load + postProcessGLTF (src/renderer/loader.ts:13-17), reduced to the fields
  * src/renderer/gpu.ts reads: nodes (children, matrix | TRS, mesh, light), mesh primitives with
  * POSITION / NORMAL / TEXCOORD_0 / indices as typed arrays, materials, KHR_lights_punctual lights.
- * Images are decoded to RGBA8 ({width, height, data}; PNG only — a JPEG texture raises an error) and texture
+ * Images are decoded to RGBA8 ({width, height, data}; PNG and JPEG) and texture
  * references are resolved the way postProcessGLTF does (`material.normalTexture.texture.source.image`), which is
  * what src/renderer/atlas.ts:36-48 walks.
  */
 var fs = require('fs');
 var decodePNG = require('./png_decode').decodePNG;
+var decodeJPEG = require('./jpeg_decode').decodeJPEG;
 
 var COMPONENTS = { 5120: Int8Array, 5121: Uint8Array, 5122: Int16Array, 5123: Uint16Array, 5125: Uint32Array, 5126: Float32Array };
 var COUNTS = { SCALAR: 1, VEC2: 2, VEC3: 3, VEC4: 4, MAT2: 4, MAT3: 9, MAT4: 16 };
@@ -58,7 +59,7 @@ function imageBytes(json, bin, img) {
 
 function decodeImage(bytes, name) {
   if (bytes.length >= 8 && bytes[0] === 137 && bytes[1] === 80) return decodePNG(bytes);
-  if (bytes.length >= 2 && bytes[0] === 0xff && bytes[1] === 0xd8) throw new Error('image "' + name + '": JPEG textures are not supported');
+  if (bytes.length >= 2 && bytes[0] === 0xff && bytes[1] === 0xd8) return decodeJPEG(bytes);
   throw new Error('image "' + name + '": unknown format');
 }
 

@@ -63,3 +63,5 @@ export const atlas: {
   packing(gltf: { materials: object[] }): PackedAtlas;
 };
 export function decodePNG(data: Uint8Array): { width: number; height: number; data: Uint8Array };
+/** jpeg_decode.js — sequential and progressive Huffman JPEG, bit-identical to libjpeg-turbo's default decode */
+export function decodeJPEG(data: Uint8Array): { width: number; height: number; data: Uint8Array };

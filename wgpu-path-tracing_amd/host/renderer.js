@@ -188,4 +188,5 @@ function setupRenderer(options) {
 }
 
 module.exports = { Renderer: Renderer, setupRenderer: setupRenderer, pack: pack, readSceneFile: sceneFile.readSceneFile,
-  atlas: require('./atlas'), decodePNG: require('./png_decode').decodePNG };
+  atlas: require('./atlas'), decodePNG: require('./png_decode').decodePNG,
+  decodeJPEG: require('./jpeg_decode').decodeJPEG };
