@@ -1,0 +1,104 @@
+"""host/controller.js restates src/renderer/controller.ts without the DOM: same key map,
+speeds, mouse / touch accumulation and per-frame update, fed by a Node EventEmitter. CPU only: a recording stand-in
+takes the place of the Renderer, plus the real camera methods of host/renderer.js on a bare camera object."""
+import json
+import math
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "wgpu-path-tracing_amd", "host")
+NODE = shutil.which("node")
+pytestmark = pytest.mark.skipif(NODE is None, reason="node is not installed")
+
+SCRIPT = """
+var EventEmitter = require('events'), C = require('./controller');
+var calls = [], fake = { moveCamera: function (f, r, u) { calls.push(['move', f, r, u]); },
+                         rotateCamera: function (y, p) { calls.push(['rotate', y, p]); } };
+var src = new EventEmitter(), c = new C.Controller(fake, src);
+JSON.parse(process.argv[1]).forEach(function (step) {
+  if (step[0] === 'update') c.update(step[1]);
+  else if (step[0] === 'destroy') c.destroy();
+  else src.emit(step[0], step[1]);
+});
+console.log(JSON.stringify({ calls: calls, listeners: src.listenerCount('keydown') }));
+"""
+
+
+def run(steps):
+    return json.loads(subprocess.check_output([NODE, "-e", SCRIPT, json.dumps(steps)], cwd=HOST, text=True))
+
+
+def test_keys_mouse_and_touch_follow_the_reference():
+    dt = 0.25
+    step = 2.0 * dt                                   # MOVE_SPEED (controller.ts:3)
+    rot = math.pi / 18 * dt                           # ROTATE_SPEED (controller.ts:4)
+    t1 = lambda x, y: {"touches": [{"clientX": x, "clientY": y}]}
+    t2 = lambda a, b: {"touches": [{"clientX": a[0], "clientY": a[1]}, {"clientX": b[0], "clientY": b[1]}]}
+    out = run([
+        ["keydown", {"key": "w"}], ["keydown", {"key": "d"}], ["keydown", {"key": "x"}], ["update", dt],
+        ["keyup", {"key": "w"}], ["keydown", {"key": "Shift"}], ["keydown", {"key": " "}], ["update", dt],
+        ["keyup", {"key": "d"}], ["keyup", {"key": "Shift"}], ["keyup", {"key": " "}],
+        ["mousemove", {"movementX": 10, "movementY": -4}], ["mousemove", {"movementX": 2, "movementY": 1}], ["update", dt],
+        ["update", dt],                                                       # nothing pending: no call
+        ["touchstart", t1(100, 100)], ["touchmove", t1(130, 90)], ["touchmove", t1(131, 95)], ["update", dt],
+        ["touchstart", t2((0, 0), (30, 40))], ["touchmove", t2((0, 0), (60, 80))],      # pinch 50 -> 100: immediate move
+        ["touchmove", t1(500, 500)],                                                    # ignored while two fingers were down
+        ["touchend", {"touches": []}], ["update", dt],
+        ["keydown", {"key": "a"}], ["keydown", {"key": "s"}], ["keydown", {"key": "q"}], ["update", dt],
+        ["destroy"], ["keydown", {"key": "w"}],
+    ])
+    want = [
+        ["move", step, 0, 0], ["move", 0, step, 0],                                      # w, d ('x' is not bound)
+        ["move", 0, step, 0], ["move", 0, 0, step], ["move", 0, 0, -step],               # d, space, Shift
+        ["rotate", 12 * -rot, -3 * -rot],
+        ["rotate", 31 * -rot, -5 * -rot],
+        ["move", 50 * 0.001, 0, 0],
+        ["move", -step, 0, 0], ["move", 0, -step, 0], ["move", 0, 0, -step],             # s, a (reference order: w s a d), q
+    ]
+    got = out["calls"]
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g[0] == w[0] and np.allclose(g[1:], w[1:], rtol=0, atol=1e-12), (g, w)
+    assert out["listeners"] == 0                       # destroy() unhooked the source
+
+
+CAMERA = """
+var R = require('./renderer').Renderer, steps = JSON.parse(process.argv[1]);
+var self = { camera: { position: [0, 1, 2.8], forward: [0, 0, -1], right: [1, 0, 0], up: [0, 1, 0] }, resets: 0,
+             resetOutputBuffer: function () { this.resets++; } };
+steps.forEach(function (s) { R.prototype[s[0]].apply(self, s.slice(1)); });
+console.log(JSON.stringify(self));
+"""
+
+
+def test_camera_methods_match_a_float64_model():
+    """moveCamera / rotateCamera of host/renderer.js (renderer.ts:152-201) on a bare camera: yaw about +Y, pitch
+    clamped to 0.99 * pi/2, right = normalize(forward x up0), up = normalize(right x forward); every call resets
+    the accumulation (renderer.ts:169, :200)."""
+    steps = [["moveCamera", 0.5, -0.25, 0.1], ["rotateCamera", 0.3, 0.2], ["moveCamera", 1.0, 0, 0],
+             ["rotateCamera", -1.1, 2.0], ["rotateCamera", 0.4, -3.5]]
+    got = json.loads(subprocess.check_output([NODE, "-e", CAMERA, json.dumps(steps)], cwd=HOST, text=True))
+    pos, f, r, u = np.array([0, 1, 2.8]), np.array([0, 0, -1.0]), np.array([1.0, 0, 0]), np.array([0, 1.0, 0])
+    for s in steps:
+        if s[0] == "moveCamera":
+            pos = pos + s[2] * r + s[1] * f + s[3] * u
+        else:
+            yaw, pitch = s[1], s[2]
+            cur = math.asin(f[1])
+            lim = math.pi / 2 * 0.99
+            dp = max(min(cur + pitch, lim), -lim) - cur
+            v1 = np.array([f[0], math.cos(dp) * f[1] - math.sin(dp) * f[2], math.sin(dp) * f[1] + math.cos(dp) * f[2]])
+            v2 = np.array([math.cos(yaw) * v1[0] + math.sin(yaw) * v1[2], v1[1], -math.sin(yaw) * v1[0] + math.cos(yaw) * v1[2]])
+            f = v2 / np.linalg.norm(v2)
+            r = np.cross(f, [0, 1, 0]); r /= np.linalg.norm(r)
+            u = np.cross(r, f); u /= np.linalg.norm(u)
+    cam = got["camera"]
+    assert got["resets"] == len(steps)
+    for name, want in (("position", pos), ("forward", f), ("right", r), ("up", u)):
+        assert np.allclose(cam[name], want, rtol=0, atol=1e-12), name
+    assert abs(np.dot(cam["forward"], cam["right"])) < 1e-12 and abs(np.linalg.norm(cam["up"]) - 1) < 1e-12

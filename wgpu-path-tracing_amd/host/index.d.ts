@@ -46,7 +46,7 @@ export class Renderer {
   setOptions(o: TraceOptions): void;
   getStats(): Stats;
 }
-export function setupRenderer(options?: { device?: number; width?: number; height?: number; model?: string; autoStart?: boolean; options?: TraceOptions }): Promise<Renderer>;
+export function setupRenderer(options?: { device?: number; width?: number; height?: number; model?: string; autoStart?: boolean; options?: TraceOptions; input?: InputSource }): Promise<Renderer>;
 export const pack: {
   packTriangles(t: TriangleCPU[]): ArrayBuffer; packMaterials(m: MaterialCPU[]): ArrayBuffer;
   packBVH(n: BVHNode[]): ArrayBuffer; packLights(l: LightCPU[]): ArrayBuffer;
@@ -65,3 +65,11 @@ export const atlas: {
 export function decodePNG(data: Uint8Array): { width: number; height: number; data: Uint8Array };
 /** jpeg_decode.js — sequential and progressive Huffman JPEG, bit-identical to libjpeg-turbo's default decode */
 export function decodeJPEG(data: Uint8Array): { width: number; height: number; data: Uint8Array };
+/** controller.js — src/renderer/controller.ts without the DOM; events keep the DOM names and payload fields */
+export interface InputSource { on(name: string, handler: (event: any) => void): void; off?(name: string, handler: (event: any) => void): void; }
+export class Controller {
+  constructor(renderer: { moveCamera(f: number, r: number, u: number): void; rotateCamera(yaw: number, pitch: number): void }, source?: InputSource);
+  handle(name: 'keydown' | 'keyup' | 'mousemove' | 'touchstart' | 'touchmove' | 'touchend' | 'touchcancel', event: any): void;
+  update(deltaTime: number): void;
+  destroy(): void;
+}

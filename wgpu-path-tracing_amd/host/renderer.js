@@ -180,13 +180,19 @@ Renderer.prototype.blit = function () {
 Renderer.prototype.setOptions = function (o) { this.addon.setOptions(this.ctx, o); };
 Renderer.prototype.getStats = function () { return this.addon.getStats(this.ctx); };
 
-/** renderer.ts:513-558 without the canvas: create, load, (optionally) start */
+/** renderer.ts:513-558 without the canvas: create, load, (optionally) start; options.input (an event source,
+ *  see controller.js) gets a Controller whose update runs every frame, like renderer.ts:554-555 */
 function setupRenderer(options) {
   var r = new Renderer(options);
+  if (options && options.input) {
+    var controller = new (require('./controller').Controller)(r, options.input);
+    r.controller = controller;
+    r.addOnUpdate(function (deltaTime) { controller.update(deltaTime); });
+  }
   if (!options || !options.model) return Promise.resolve(r);
   return r.loadModel(options.model).then(function () { if (options.autoStart) r.start(); return r; });
 }
 
 module.exports = { Renderer: Renderer, setupRenderer: setupRenderer, pack: pack, readSceneFile: sceneFile.readSceneFile,
   atlas: require('./atlas'), decodePNG: require('./png_decode').decodePNG,
-  decodeJPEG: require('./jpeg_decode').decodeJPEG };
+  decodeJPEG: require('./jpeg_decode').decodeJPEG, Controller: require('./controller').Controller };
