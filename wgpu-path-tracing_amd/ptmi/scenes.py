@@ -306,6 +306,46 @@ def feature_box():
     return _finish("feature_box", parts, mats, punctual=punctual, atlas=atlas)
 
 
+def random_soup(seed, n_tris=400):
+    """Seeded random scene for fuzzing the parity of the whole path: triangles of mixed sizes inside [-1,1] x [0,2] x
+    [-1,1] with un-normalised, sometimes flipped or zero vertex normals, a few degenerate triangles (zero area,
+    repeated vertices), random materials (every lobe, some textured), one emissive material, and a point plus an
+    axis-aligned directional light (its shadow rays have zero direction components)."""
+    rng = np.random.default_rng(seed)
+    atlas, rects = _procedural_atlas(size=128, tile=32, n_sets=1)
+    r = rects[0]
+    mats = [_material(_WHITE, emission=(1, 0.95, 0.9), strength=6.0)]
+    for k in range(9):
+        lobe = k % 3
+        mats.append(_material(tuple(rng.random(3) * 0.8 + 0.1),
+                              metallic=float(rng.random()) if lobe == 1 else 0.0,
+                              roughness=float(rng.choice([0.0, 0.02, 0.3, 1.0])),
+                              transmission=float(rng.choice([1.0, 0.5])) if lobe == 2 else 0.0,
+                              ior=float(rng.choice([1.0, 1.33, 1.5, 2.4])),
+                              albedo_map=r["albedo"] if k in (3, 4) else None,
+                              pbr_map=r["pbr"] if k == 4 else None, normal_map=r["normal"] if k in (4, 5) else None))
+    c = rng.random((n_tris, 1, 3)) * np.array([2.0, 2.0, 2.0]) + np.array([-1.0, 0.0, -1.0])
+    size = rng.choice([0.02, 0.1, 0.4, 1.5], size=(n_tris, 1, 1), p=[0.2, 0.5, 0.25, 0.05])
+    v = (c + (rng.random((n_tris, 3, 3)) - 0.5) * size).astype(np.float32)
+    v[0::37, 1] = v[0::37, 0]                                   # repeated vertex
+    v[5::41, 2] = (v[5::41, 0] + v[5::41, 1]) / 2               # collinear
+    geo = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
+    n = np.repeat(geo[:, None, :], 3, 1) + (rng.random((n_tris, 3, 3)) - 0.5) * 0.3 * np.abs(geo).max()
+    n[3::29] *= -1.0                                            # shading normal opposite to the geometric one
+    n[7::53] = 0.0                                              # zero normals: normalize() gives NaN, as in the reference
+    uv = (rng.random((n_tris, 3, 2)) * 3 - 1).astype(np.float32)
+    mat = rng.integers(1, len(mats), n_tris)
+    mat[:6] = 0                                                 # six emissive triangles
+    tris = _tri_array(v, n.astype(np.float32), uv, mat)
+    floor = _quad((-1.2, -0.01, -1.2), (1.2, -0.01, -1.2), (1.2, -0.01, 1.2), (-1.2, -0.01, 1.2), (0, 1, 0), 1)
+    punctual = np.zeros(2, layout.LIGHT)
+    punctual[0]["position"], punctual[0]["light_type"] = tuple(rng.random(3) * [1.6, 0.5, 1.6] + [-0.8, 1.6, -0.8]), layout.LIGHT_POINT
+    punctual[0]["color"], punctual[0]["intensity"] = (1.0, 0.9, 0.8), 3.0
+    punctual[1]["position"], punctual[1]["light_type"] = (0.0, -1.0, 0.0), layout.LIGHT_DIRECTIONAL
+    punctual[1]["color"], punctual[1]["intensity"] = (0.7, 0.8, 1.0), 1.0
+    return _finish("random_soup_%d" % seed, [tris, floor], mats, punctual=punctual, atlas=atlas)
+
+
 SCENES = {"cornell": cornell, "cornell_glass": lambda: cornell(glass=True),
           "cornell_spheres": cornell_spheres, "grid_1m": grid_1m, "feature_box": feature_box}
 
