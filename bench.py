@@ -10,10 +10,11 @@ batch of 66 M paths) over the rank's rows; the default K = 2 steps therefore ren
 live in HBM before the timed region starts (the C ABI copies host blobs at upload).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling over pixel rows —
-the frame is 1920 x (1080*N), rank r renders rows [1080 r, 1080 (r+1)) with no data-path
-collective (pixels and RNG streams are independent, pt.wgsl:719, :753-761); after every
-step the bands are gathered to rank 0 with one RCCL gather. value = all ranks' path
-segments / max-over-ranks time.
+the same view at N times the pixels (1920x1080, 2720x1528, 3840x2160, 5424x3040: same aspect,
+so the same mix of cheap and expensive pixels per rank), rank r renders the 4-row strips
+r, r + N, ... with no data-path collective (pixels and RNG streams are independent,
+pt.wgsl:719, :753-761); after the last step the strips are gathered to rank 0 with ONE RCCL
+gather, inside the timed region. value = all ranks' path segments / max-over-ranks time.
 
 Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel (closest-hit
 traversal `extend`) against HBM: algorithmic bytes per ray = 32 (origin+direction
@@ -134,8 +135,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     mis = 0 if args.no_mis else 1
-    W, H = args.width, args.height * world
-    y0, y1 = shard.band(H, world, rank)
+    # Weak scaling: the SAME view at `world` times the pixels (1920x1080 -> 2720x1528 -> 3840x2160 -> 5424x3040), so
+    # the mix of cheap and expensive pixels does not change with N; rank r renders the 4-row strips r, r + N, ...
+    # (an even sample of the picture: no rank is stuck with the expensive rows), gathered once at the end.
+    W, H = shard.weak_frame(args.width, args.height, world)
     scene = scenes.make(args.scene)
 
     ctx = native.Context(local_rank)
@@ -151,8 +154,8 @@ def main():
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
     trav = {"auto": native.TRAVERSAL_AUTO, "global": native.TRAVERSAL_GLOBAL, "lds": native.TRAVERSAL_LDS}[args.traversal]
-    ctx.set_options(max_bounces=args.bounces, do_mis=mis, tile_y0=y0, tile_y1=y1,
-                    frames_per_batch=args.frames_per_batch, traversal=trav, cull=1, timing=args.timing)
+    ctx.set_options(max_bounces=args.bounces, do_mis=mis, frames_per_batch=args.frames_per_batch, traversal=trav, cull=1,
+                    timing=args.timing, **shard.strip_options(world, rank))
 
     fps = args.frames_per_step
     frame_index = 0
@@ -166,11 +169,11 @@ def main():
         # the bands accumulate locally; ONE gather assembles the frame after the last frame
         if world > 1 and args.rehearse:
             host = frame.cpu()
-            shard.gather_bands(dist, host, H, world, rank)
+            shard.gather_strips(dist, host, world, rank)
             if rank == 0:
                 frame.copy_(host)
         elif world > 1:
-            shard.gather_bands(dist, frame, H, world, rank)
+            shard.gather_strips(dist, frame, world, rank)
 
     def fence():
         if world > 1:
@@ -194,7 +197,7 @@ def main():
     if args.rehearse and rank == 0:
         # the same frames, unsharded, on this rank alone: the sharded + gathered frame must equal it bit for bit
         gathered = frame.cpu().numpy().copy()
-        ctx.set_options(tile_y0=0, tile_y1=0, timing=0)
+        ctx.set_options(tile_y0=0, tile_y1=0, tile_parts=0, tile_part=0, timing=0)
         frame.zero_()
         for k in range(args.warmup + args.steps):
             ctx.dispatch(layout.make_camera(W, H, frame_index=k * fps), fps)
@@ -221,11 +224,11 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"{args.scene} {W}x{args.height} per GPU, {args.steps * fps} spp, {args.bounces} bounces, "
+                "workload": f"{args.scene} {args.width}x{args.height} pixels per GPU, {args.steps * fps} spp, {args.bounces} bounces, "
                             f"MIS {'on' if mis else 'off'} (BASELINE.json configs[1]); frame {W}x{H}",
                 "frames_per_step": fps, "frames_per_batch": int(st.frames_per_batch_used),
                 "traversal": "lds" if st.traversal_used == native.TRAVERSAL_LDS else "global",
-                "triangles": int(len(scene.tris)), "bvh_nodes": int(len(scene.nodes)), "parallelism": f"rows x{world}",
+                "triangles": int(len(scene.tris)), "bvh_nodes": int(len(scene.nodes)), "parallelism": f"{shard.STRIP_ROWS}-row strips x{world}",
             },
             **({"rehearsal": {"sharded_equals_unsharded_bitwise": rehearsal_ok, "backend": "gloo", "note": "all ranks on one GPU; not a benchmark"}} if args.rehearse else {}),
             "segments": int(segments), "shadow_rays": int(shadow_rays), "paths": int(paths),

@@ -59,7 +59,11 @@ typedef struct ptmi_options {
     uint32_t keep_reference_tree; /* read by ptmi_upload_scene. 0 (default): when every node box of the uploaded BVH contains
                                    its children's boxes, traversal walks a SAH hierarchy rebuilt over the SAME leaves (same
                                    results, about half the box tests); 1: always walk the tree as uploaded */
-    uint32_t reserved[7];
+    uint32_t tile_parts, tile_part, tile_strip; /* interleaved row sharding: with tile_parts = N > 1 this context renders, of the
+                                   rows [tile_y0, tile_y1), the strips of tile_strip rows (0 -> 1) numbered tile_part,
+                                   tile_part + N, ... — N contexts with tile_part = 0..N-1 cover the range exactly once, each
+                                   with an even sample of the picture. 0 / 1 = all rows of the range (default) */
+    uint32_t reserved[4];
 } ptmi_options;
 
 typedef struct ptmi_stats {

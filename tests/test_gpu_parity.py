@@ -309,3 +309,31 @@ def test_random_scene_fuzz(gpu_ctx, oracle, seed):
         assert_same_floats(got, ref, f"radiance (seed {seed}, keep {keep}, traversal {trav})")
     gpu_ctx.set_options(keep_reference_tree=0, traversal=native.TRAVERSAL_AUTO)
     assert np.nanmean(ref[..., :3]) > 0.005
+
+
+@pytest.mark.parametrize("parts,strip,rows", [(3, 4, (0, 0)), (2, 1, (0, 0)), (4, 5, (7, 58)), (8, 4, (0, 0)), (70, 1, (0, 0))])
+def test_interleaved_strips_cover_the_frame(gpu_ctx, oracle, scene_factory, parts, strip, rows):
+    """tile_parts / tile_part / tile_strip (include/ptmi.h): N contexts with tile_part = 0..N-1 render disjoint
+    strips that together are the single render, bit for bit — also with a short last strip, a sub-range of rows and
+    more parts than strips."""
+    sc = scene_factory("cornell")
+    W, H, frames = 64, 60, 3
+    cam = layout.make_camera(W, H)
+    ref, ost = oracle.render(sc, cam, frames)
+    gpu_ctx.upload_scene(sc)
+    gpu_ctx.resize(W, H)
+    gpu_ctx.set_options(max_bounces=8, do_mis=1, frames_per_batch=0, tile_y0=rows[0], tile_y1=rows[1], tile_parts=parts,
+                        tile_strip=strip)
+    gpu_ctx.reset_stats()
+    for part in range(parts):
+        gpu_ctx.set_options(tile_part=part)
+        gpu_ctx.dispatch(cam, frames)
+    got = gpu_ctx.read_output()
+    y0, y1 = rows[0], rows[1] or H
+    assert_same_floats(got[y0:y1], ref[y0:y1], f"strips parts={parts} strip={strip}")
+    assert not got[:y0].any() and not got[y1:].any()
+    if rows == (0, 0):
+        assert gpu_ctx.stats().segments == ost.segments
+    with pytest.raises(Exception):
+        gpu_ctx.set_options(tile_parts=2, tile_part=2)
+    gpu_ctx.set_options(tile_y0=0, tile_y1=0, tile_parts=0, tile_part=0, tile_strip=0)

@@ -26,6 +26,8 @@ def test_two_ranks_one_gpu_sharded_equals_unsharded():
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "rows x2"
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "4-row strips x2"
     assert d["rehearsal"]["sharded_equals_unsharded_bitwise"] is True
-    assert d["paths"] == 640 * 360 * 8 and d["value"] > 0
+    from ptmi import shard
+    w, h = shard.weak_frame(640, 180, 2)                      # same view, twice the pixels
+    assert d["paths"] == w * h * 8 and d["value"] > 0

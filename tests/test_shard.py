@@ -71,3 +71,58 @@ def test_two_rank_gloo_gather_equals_single_render(H):
         p.join(300)
         assert p.exitcode == 0
     assert q.get(timeout=10) is True
+
+
+def test_weak_frame_keeps_the_view_and_the_work_per_rank():
+    for N in (1, 2, 4, 8):
+        w, h = shard.weak_frame(1920, 1080, N)
+        assert h % (shard.STRIP_ROWS * N) == 0 and w % 16 == 0
+        assert abs(w / h - 16 / 9) < 0.01                                  # same aspect -> same picture
+        assert abs(w * h / N / (1920 * 1080) - 1) < 0.01                   # same pixels per rank
+    assert shard.weak_frame(1920, 1080, 1) == (1920, 1080) and shard.weak_frame(1920, 1080, 4) == (3840, 2160)
+    assert shard.strip_options(1, 0)["tile_parts"] == 0
+    assert shard.strip_options(8, 5) == dict(tile_y0=0, tile_y1=0, tile_parts=8, tile_part=5, tile_strip=shard.STRIP_ROWS)
+    with pytest.raises(ValueError):
+        shard.strip_options(4, 4)
+
+
+def _strip_worker(rank, world, port, H, W, frames, q):
+    sys.path.insert(0, os.path.join(ROOT, "wgpu-path-tracing_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from oracle_lib import Oracle
+    from ptmi import layout, scenes, shard as sh
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc = scenes.make("cornell")
+        cam = layout.make_camera(W, H)
+        frame = np.zeros((H, W, 4), np.float32)
+        o, strip = Oracle(), sh.STRIP_ROWS
+        for y0 in range(rank * strip, H, world * strip):                          # this rank's strips only
+            o.render(sc, cam, frames, out=frame, y0=y0, y1=y0 + strip, threads=2)
+        t = torch.from_numpy(frame)
+        sh.gather_strips(dist, t, world, rank)
+        dist.barrier()
+        if rank == 0:
+            full, _ = Oracle().render(sc, cam, frames, threads=2)
+            q.put(bool(np.array_equal(t.numpy().view(np.uint32), full.view(np.uint32))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_strip_gather_equals_single_render():
+    """Interleaved strips (the bench's weak-scaling shard unit): rank r renders strips r, r + 2, ...; one gather
+    de-interleaves them into the frame of a single render."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_strip_worker, args=(r, 2, port, 32, 40, 2, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) is True

@@ -45,16 +45,16 @@ PT_DEV void init_path(DevPaths P, uint32_t p, v3 o, v3 d, uint32_t rng) {
     P.L[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);      // pt.wgsl:640
 }
 
-// path id = frame_in_batch * band_pixels + (y - y0) * width + x. The bounce-0 queue is the identity and is
+// path id = frame_in_batch * band_pixels + local_row * width + x (local rows: DevBand::row_of). The bounce-0 queue is the identity and is
 // not materialised: extend / shade / compact take a null queue as "slot i holds path i".
 __global__ __launch_bounds__(BLOCK) void k_raygen(ptmi_camera cam, DevBand band, uint32_t frame0, uint32_t n_frames,
                                                   DevPaths P, uint32_t *__restrict__ count_out) {
-    const uint32_t npix = (band.y1 - band.y0) * band.width;
+    const uint32_t npix = band.rows * band.width;
     const uint32_t total = npix * n_frames;
     if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = total;
     for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < total; p += gridDim.x * BLOCK) {
         uint32_t k = p / npix, pix = p - k * npix;
-        uint32_t y = band.y0 + pix / band.width, x = pix % band.width;
+        uint32_t y = band.row_of(pix / band.width), x = pix % band.width;
         v3 o, d; uint32_t rng;
         camera_ray(cam, x, y, frame0 + k, o, d, rng);
         init_path(P, p, o, d, rng);
@@ -165,9 +165,9 @@ __global__ __launch_bounds__(TILE_WORDS) void k_scatter(const uint32_t *__restri
 // pt.wgsl:751-761 for the batch's frames in ascending order
 __global__ __launch_bounds__(BLOCK) void k_accumulate(DevBand band, uint32_t frame0, uint32_t n_frames,
                                                       const float4 *__restrict__ L, float4 *__restrict__ out) {
-    const uint32_t npix = (band.y1 - band.y0) * band.width;
+    const uint32_t npix = band.rows * band.width;
     for (uint32_t pix = blockIdx.x * BLOCK + threadIdx.x; pix < npix; pix += gridDim.x * BLOCK) {
-        const size_t oi = (size_t)band.y0 * band.width + pix;
+        const size_t oi = (size_t)band.row_of(pix / band.width) * band.width + pix % band.width;
         float4 acc = out[oi];
         for (uint32_t k = 0; k < n_frames; k++) {
             float4 l = L[(size_t)k * npix + pix];

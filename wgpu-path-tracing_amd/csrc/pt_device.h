@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include "ptmi_layout.h"
 
+#define PT_HD __host__ __device__ inline
+
 // ---- traversal image of the scene (built at upload from the 48-B reference nodes) ----
 // Wide node, 64 B = 4 x float4: both children's boxes live in the parent, so one
 // fetch decides both subtrees.
@@ -46,7 +48,16 @@ struct DevPaths { float4 *O, *D, *T, *L; };
 //   SC = (throughput * directLight .xyz, 0)   added to L[path] when unoccluded
 struct DevShadow { float4 *SO, *SD, *SC; };
 
-struct DevBand { uint32_t width, height, y0, y1; };      // rows [y0,y1) of a width x height frame
+// The rows one context renders: [y0, y1) of a width x height frame, or — when parts > 1 — every parts-th strip
+// of `strip` rows inside that range, starting with strip number `part` (row bands interleaved across GPUs so each
+// sees a sample of the whole picture). rows = how many rows that is; local row l is frame row row_of(l).
+struct DevBand {
+    uint32_t width, height, y0, y1, strip, parts, part, rows;
+    PT_HD uint32_t row_of(uint32_t l) const {
+        if (parts <= 1u) return y0 + l;
+        return y0 + ((l / strip) * parts + part) * strip + l % strip;
+    }
+};
 
 struct ShadeParams {
     uint32_t bounce, max_bounces, do_mis;

@@ -405,6 +405,8 @@ int ptmi_set_options(ptmi_ctx *c, const ptmi_options *o) {
     if (o->max_bounces < 1 || o->max_bounces > 64) return fail(c, PTMI_E_INVALID, "max_bounces %u not in 1..64", o->max_bounces);
     if (o->traversal > PTMI_TRAVERSAL_LDS) return fail(c, PTMI_E_INVALID, "unknown traversal mode %u", o->traversal);
     if (o->tile_y1 != 0 && o->tile_y0 >= o->tile_y1) return fail(c, PTMI_E_INVALID, "empty tile rows [%u,%u)", o->tile_y0, o->tile_y1);
+    if (o->tile_parts > 1 && o->tile_part >= o->tile_parts)
+        return fail(c, PTMI_E_INVALID, "tile_part %u is not below tile_parts %u", o->tile_part, o->tile_parts);
     c->opt = *o;
     return PTMI_OK;
 }
@@ -421,9 +423,18 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
         return fail(c, PTMI_E_INVALID, "camera says %ux%u but the output buffer is %ux%u", cam->width, cam->height, c->W, c->H);
     if (n_frames == 0) return PTMI_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    DevBand band{c->W, c->H, c->opt.tile_y0, c->opt.tile_y1 ? std::min(c->opt.tile_y1, c->H) : c->H};
+    DevBand band{c->W, c->H, c->opt.tile_y0, c->opt.tile_y1 ? std::min(c->opt.tile_y1, c->H) : c->H,
+                 std::max(1u, c->opt.tile_strip), std::max(1u, c->opt.tile_parts), c->opt.tile_part, 0u};
     if (band.y0 >= band.y1) return fail(c, PTMI_E_INVALID, "tile rows [%u,%u) outside the %u-row frame", band.y0, band.y1, c->H);
-    const uint64_t npix = (uint64_t)(band.y1 - band.y0) * band.width;
+    {   // rows of this context: all of [y0, y1), or its strips part, part + parts, ... (the last strip may be short)
+        const uint32_t range = band.y1 - band.y0;
+        if (band.parts <= 1u) band.rows = range;
+        else
+            for (uint32_t s0 = band.part * band.strip; s0 < range; s0 += band.parts * band.strip)
+                band.rows += std::min(band.strip, range - s0);
+        if (band.rows == 0) return PTMI_OK;                     // more parts than strips: nothing to render here
+    }
+    const uint64_t npix = (uint64_t)band.rows * band.width;
     uint32_t F = c->opt.frames_per_batch;
     if (F == 0) { F = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, (64ull << 20) / npix)); }   // ~64 Mi paths, ~10 GB of state
     F = std::min(F, n_frames);

@@ -164,6 +164,9 @@ static napi_value js_set_options(napi_env env, napi_callback_info info) {
     o.cull = get_u32_prop(env, argv[1], "cull", o.cull);
     o.timing = get_u32_prop(env, argv[1], "timing", o.timing);
     o.keep_reference_tree = get_u32_prop(env, argv[1], "keepReferenceTree", o.keep_reference_tree);
+    o.tile_parts = get_u32_prop(env, argv[1], "tileParts", o.tile_parts);
+    o.tile_part = get_u32_prop(env, argv[1], "tilePart", o.tile_part);
+    o.tile_strip = get_u32_prop(env, argv[1], "tileStrip", o.tile_strip);
     int rc = ptmi_set_options(ctx, &o);
     if (rc) return throw_ptmi(env, ctx, rc, "ptmi_set_options");
     return NULL;

@@ -23,6 +23,7 @@ export interface Atlas { data: ArrayBuffer; width: number; height: number; forma
 export interface TraceOptions {
   maxBounces?: number; doMis?: number; tileY0?: number; tileY1?: number; framesPerBatch?: number;
   traversal?: 0 | 1 | 2; cull?: number; timing?: number; keepReferenceTree?: number;
+  tileParts?: number; tilePart?: number; tileStrip?: number;
 }
 export interface Stats {
   paths: number; segments: number; shadowRays: number; frames: number; dispatches: number;

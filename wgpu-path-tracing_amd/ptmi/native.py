@@ -36,7 +36,8 @@ class Options(ctypes.Structure):
                 ("tile_y0", ctypes.c_uint32), ("tile_y1", ctypes.c_uint32),
                 ("frames_per_batch", ctypes.c_uint32), ("traversal", ctypes.c_uint32),
                 ("cull", ctypes.c_uint32), ("timing", ctypes.c_uint32), ("keep_reference_tree", ctypes.c_uint32),
-                ("reserved", ctypes.c_uint32 * 7)]
+                ("tile_parts", ctypes.c_uint32), ("tile_part", ctypes.c_uint32), ("tile_strip", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32 * 4)]
 
 
 class Stats(ctypes.Structure):

@@ -42,3 +42,47 @@ def gather_bands(dist, frame, height, world, rank, dst=0):
             if r != dst:
                 frame[a:b] = gl[r][: b - a]
     return frame
+
+
+# ---- interleaved strips ("if imbalance shows, switch to 16-row strips assigned round-robin and
+# de-interleave after the gather") -----------------------------------------------------------------------------
+STRIP_ROWS = 4
+
+
+def weak_frame(base_width, base_height, world, strip=STRIP_ROWS):
+    """Frame of `world` times the pixels of base_width x base_height with the SAME aspect (so the same view and the
+    same mix of cheap and expensive pixels at every world size), its height a whole number of strip rounds."""
+    if world == 1:
+        return base_width, base_height
+    s = world ** 0.5
+    rnd = strip * world
+    h = max(rnd, int(round(base_height * s / rnd)) * rnd)
+    w = max(16, int(round(base_width * s / 16)) * 16)
+    return w, h
+
+
+def strip_options(world, rank, strip=STRIP_ROWS):
+    """ptmi options (include/ptmi.h) that make rank `rank` render strips rank, rank + world, ... of the frame."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside world {world}")
+    return dict(tile_y0=0, tile_y1=0, tile_parts=world if world > 1 else 0, tile_part=rank if world > 1 else 0,
+                tile_strip=strip)
+
+
+def gather_strips(dist, frame, world, rank, strip=STRIP_ROWS, dst=0):
+    """frame: (height, width, 4) tensor whose strips rank, rank + world, ... are valid on rank `rank`
+    (height % (strip * world) == 0). ONE gather; afterwards rank `dst` holds the complete frame."""
+    if world == 1:
+        return frame
+    h = frame.shape[0]
+    if h % (strip * world):
+        raise ValueError(f"{h} rows are not a whole number of rounds of {world} strips of {strip} rows")
+    rounds = frame.view(h // (strip * world), world, strip, *frame.shape[1:])   # [round, owner, row in strip, x, c]
+    mine = rounds[:, rank].contiguous()
+    recv = [mine.new_empty(mine.shape) for _ in range(world)] if rank == dst else None
+    dist.gather(mine, recv, dst=dst)
+    if rank == dst:
+        for r in range(world):
+            if r != dst:
+                rounds[:, r] = recv[r]
+    return frame
