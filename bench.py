@@ -65,6 +65,21 @@ def pmc_traffic(default_workload):
     return int((2 * f + w) * 1024)
 
 
+def valu_issue(avg_launch_ms, default_workload):
+    """SIMD cycles per VALU wave-instruction of the extend kernel: instructions per launch from the committed
+    rocprofv3 --pmc SQ_INSTS_VALU pass (profiles/r01_bench_n1_valu.json), duration measured live."""
+    path = os.path.join(ROOT, "profiles", "r01_bench_n1_valu.json")
+    if not default_workload or not os.path.exists(path) or not avg_launch_ms:
+        return None
+    try:
+        n = json.load(open(path))["SQ_INSTS_VALU"]["k_trace_lds/extend"]["avg_per_launch"]
+    except KeyError:
+        return None
+    return {"wave_instructions_per_launch": int(n),
+            "simd_cycles_per_instruction": round(avg_launch_ms * 1e-3 * 2.4e9 * 1024 / n, 3),
+            "microbenchmark_cycles_per_instruction": 3.0}
+
+
 def cpu_baseline(scene, width, height, bounces, mis, threads, target_s=12.0):
     """Oracle on whole frames of the same camera: 1 calibration frame, then as many frames as
     fit in about target_s seconds (at most the 64 of the workload)."""
@@ -250,6 +265,11 @@ def main():
                 "pipeline_bytes_per_segment": round(b_seg, 1),
                 "pipeline_achieved": round(msamples * 1e6 * b_seg / 1e9, 3),
                 "pipeline_frac": round(msamples * 1e6 * b_seg / 1e9 / HBM_PEAK_GBS, 6),
+                # why frac is low: the kernel saturates the vector ALUs, not HBM (scene in LDS / L2). VALU instructions per
+                # launch from the committed SQ_INSTS_VALU pass of this command; cycles at the nominal 2.4 GHz over 1024 SIMDs
+                # (a VALU microbenchmark, tools/ubench/pk.hip, issues one per 3.0 cycles per SIMD at this occupancy)
+                "valu": valu_issue(ext_ms, args.scene == "cornell" and W == 1920 and args.height == 1080 and fps == 32
+                                   and world == 1 and args.traversal == "auto" and mis and args.bounces == 8),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

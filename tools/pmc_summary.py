@@ -31,7 +31,7 @@ def to_json(paths):
             a[0] += 1
             a[1] += float(r['Counter_Value'])
     for (c, k), (n, s) in sorted(acc.items()):
-        out[c][k] = {"launches": n, "avg_KB_per_launch": round(s / n, 2)}
+        out[c][k] = {"launches": n, ("avg_KB_per_launch" if c.endswith("_SIZE") else "avg_per_launch"): round(s / n, 2)}
     return json.dumps(out, indent=1)
 
 

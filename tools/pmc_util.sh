@@ -8,7 +8,7 @@ python3 - <<'PY'
 import json
 d=json.load(open('gpurun_out/pmc_util/util.json'))
 for k in sorted(d.get('SQ_ACTIVE_INST_VALU',{})):
-    a=d['SQ_ACTIVE_INST_VALU'][k]['avg_KB_per_launch']*1024; t=d['SQ_THREAD_CYCLES_VALU'][k]['avg_KB_per_launch']*1024
-    v=d['SQ_INSTS_VALU'][k]['avg_KB_per_launch']*1024; s=d['SQ_INSTS_SALU'][k]['avg_KB_per_launch']*1024
+    a=d['SQ_ACTIVE_INST_VALU'][k]['avg_per_launch']; t=d['SQ_THREAD_CYCLES_VALU'][k]['avg_per_launch']
+    v=d['SQ_INSTS_VALU'][k]['avg_per_launch']; s=d['SQ_INSTS_SALU'][k]['avg_per_launch']
     print(f"{k:22s} lane utilisation {t/(a*64) if a else 0:.3f}  VALU/launch {v:.3e}  SALU/launch {s:.3e}  active cycles per VALU {a/v if v else 0:.2f}")
 PY
