@@ -91,3 +91,30 @@ def test_configs4_shape_4k_depth_of_field_eight_shares(gpu_ctx, oracle, scene_fa
     assert same(gpu_ctx.read_output(), full) and sum(seg) == st.segments
     assert max(seg) / (sum(seg) / 8) < 1.02                                 # the shares are balanced to 2 %
     gpu_ctx.set_options(tile_parts=0, tile_part=0, tile_strip=0)
+
+
+@pytest.mark.parametrize("name,frames,rows", [("cornell_spheres", 64, ((400, 403),)),      # configs[2]: textured PBR spheres, 1024^2 atlas
+                                              ("grid_1m", 16, ((300, 302),))])            # configs[3]: 999 708 triangles, depth-29 BVH
+def test_configs2_and_3_scenes_at_1080p(gpu_ctx, oracle, scene_factory, name, frames, rows):
+    """The two larger scenes of BASELINE.json at full resolution (fewer frames than the configs ask for: the checks
+    are per frame), global-memory traversal: oracle row crops, ragged batches, interleaved shares."""
+    sc = scene_factory(name)
+    W, H = 1920, 1080
+    cam = layout.make_camera(W, H)
+    gpu_ctx.upload_scene(sc)
+    full, st = render(gpu_ctx, cam, frames)
+    assert st.paths == W * H * frames and st.traversal_used == native.TRAVERSAL_GLOBAL
+    assert np.isfinite(full).all() and full[..., :3].mean() > 0.02
+    for y0, y1 in rows:
+        ref = np.zeros((H, W, 4), np.float32)
+        oracle.render(sc, cam, frames, out=ref, y0=y0, y1=y1)
+        assert same(full[y0:y1], ref[y0:y1]), f"{name}: rows {y0}..{y1} differ from the oracle"
+    ragged, st2 = render(gpu_ctx, cam, frames, frames_per_batch=5)
+    assert same(ragged, full) and st2.segments == st.segments
+    gpu_ctx.resize(W, H)
+    gpu_ctx.reset_stats()
+    for part in range(2):
+        gpu_ctx.set_options(tile_parts=2, tile_part=part, tile_strip=4)
+        gpu_ctx.dispatch(cam, frames)
+    assert same(gpu_ctx.read_output(), full) and gpu_ctx.stats().segments == st.segments
+    gpu_ctx.set_options(tile_parts=0, tile_part=0, tile_strip=0)
