@@ -232,7 +232,7 @@ int build_image(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_
 }
 
 // per-lane LDS entries: the node stack (<= depth - 2 deferred siblings) plus room for filed leaves
-int stack_entries_for(uint32_t depth) { return depth + 2 <= 16 ? 16 : depth + 2 <= 32 ? 32 : 64; }
+int stack_entries_for(uint32_t depth) { return depth + 2 <= 16 ? 16 : depth + 2 <= 24 ? 24 : depth + 2 <= 32 ? 32 : 64; }
 
 // closest_hit: the extend kernel may take the node-cache variant (two workgroups per CU) when it fits
 TraverseConfig traverse_config(const ptmi_ctx *c, bool closest_hit) {
@@ -241,14 +241,16 @@ TraverseConfig traverse_config(const ptmi_ctx *c, bool closest_hit) {
     cfg.cull = c->opt.cull ? 1 : 0;
     cfg.lds_scene_bytes = c->lds_scene_bytes;
     const bool have = c->sc.root_ref != PT_REF_NONE;
-    const bool fits = have && cfg.stack_entries <= 32 && c->lds_scene_bytes + (size_t)cfg.stack_entries * 1024 * 4 <= kLdsMax;
+    const int lds_stack = cfg.stack_entries <= 16 ? 16 : 32;              // the sizes the LDS kernels are built for
+    const bool fits = have && cfg.stack_entries <= 32 && c->lds_scene_bytes + (size_t)lds_stack * 1024 * 4 <= kLdsMax;
     const int small_stack = c->bvh_depth + 1 <= 15 ? 15 : 16;  // node stack <= depth - 2, plus >= 3 entries for filed leaves
     const bool node_cache = have && c->bvh_depth + 2 <= 16 &&
                             (size_t)c->sc.n_wnodes * 64 + (size_t)small_stack * 1024 * 4 <= kLdsMax / 2;
     if (c->opt.traversal == PTMI_TRAVERSAL_GLOBAL) cfg.variant = PT_VARIANT_GLOBAL;
     else if (closest_hit && node_cache && c->opt.traversal == PTMI_TRAVERSAL_AUTO) {   // any-hit: measured 15 % slower with it
         cfg.variant = PT_VARIANT_LDS_NODES; cfg.stack_entries = small_stack;
-    } else cfg.variant = fits ? PT_VARIANT_LDS : PT_VARIANT_GLOBAL;
+    } else if (fits) { cfg.variant = PT_VARIANT_LDS; cfg.stack_entries = lds_stack; }
+    else cfg.variant = PT_VARIANT_GLOBAL;
     return cfg;
 }
 

@@ -367,6 +367,20 @@ void launch_lds(hipStream_t s, int wgs, size_t bytes, const DevScene &sc, const 
     hipLaunchKernelGGL((k_trace_lds<MODE, CULL, STACK, TRIS, IO>), dim3(wgs), dim3(LBLOCK), bytes, s, sc, io, count);
 }
 
+// The persistent grid of the global variant is the workgroups that run at once; what limits them is the LDS the
+// per-lane stacks take (16 / 24 / 32 / 64 entries x 256 lanes x 4 B). Measured (extend, ms per 64 spp, workgroups per CU):
+//   cornell_spheres, 24 entries: 4: 30.1  5: 27.7  6: 25.0  7: 33.0  8: 31.2  12: 25.7   -> 6 = floor(160 KB / 24 KB)
+//   grid_1m,         32 entries: 3: 27.5  4: 23.8  5: 32.5  8: 26.3  16: 32.2           -> 4, although 5 x 32 KB = 160 KB
+// A grid one workgroup per CU too large runs a second, almost empty round (each workgroup carries a full share of
+// the queue), so the count keeps one byte of LDS spare: 8 / 6 / 4 / 2 per CU.
+template <int MODE, bool CULL, int STACK, class IO>
+void launch_global(hipStream_t s, int cus, const DevScene &sc, const IO &io, const uint32_t *count) {
+    constexpr int lds_bytes = STACK * GBLOCK * 4;
+    constexpr int by_lds = (160 * 1024 - 1) / lds_bytes;
+    constexpr int per_cu = by_lds < 1 ? 1 : by_lds < 8 ? by_lds : 8;
+    hipLaunchKernelGGL((k_trace_global<MODE, CULL, STACK, IO>), dim3(per_cu * cus), dim3(GBLOCK), 0, s, sc, io, count);
+}
+
 template <int MODE, bool CULL, class IO>
 void launch(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, const IO &io,
             const uint32_t *count) {
@@ -381,11 +395,13 @@ void launch(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene
         if (cfg.stack_entries <= 16) launch_lds<MODE, CULL, 16, true>(s, cus, bytes, sc, io, count);
         else launch_lds<MODE, CULL, 32, true>(s, cus, bytes, sc, io, count);
     } else if (cfg.stack_entries <= 16) {
-        hipLaunchKernelGGL((k_trace_global<MODE, CULL, 16, IO>), dim3(blocks), dim3(GBLOCK), 0, s, sc, io, count);
+        launch_global<MODE, CULL, 16>(s, cus, sc, io, count);
+    } else if (cfg.stack_entries <= 24) {
+        launch_global<MODE, CULL, 24>(s, cus, sc, io, count);
     } else if (cfg.stack_entries <= 32) {
-        hipLaunchKernelGGL((k_trace_global<MODE, CULL, 32, IO>), dim3(blocks), dim3(GBLOCK), 0, s, sc, io, count);
+        launch_global<MODE, CULL, 32>(s, cus, sc, io, count);
     } else {
-        hipLaunchKernelGGL((k_trace_global<MODE, CULL, 64, IO>), dim3(blocks), dim3(GBLOCK), 0, s, sc, io, count);
+        launch_global<MODE, CULL, 64>(s, cus, sc, io, count);
     }
 }
 
