@@ -129,3 +129,41 @@ def test_upload_validation_is_loud(gpu_ctx, scene_factory):
     with pytest.raises(native.PtmiError):
         gpu_ctx.upload_scene(leafy)
     gpu_ctx.upload_scene(sc)
+
+
+def test_deep_tree_spills_the_node_stack(gpu_ctx, oracle, scene_factory):
+    """scenes.deep_chain: a 35-level BVH. The global variant keeps 16 stack entries per lane in LDS and moves the rest
+    of a deep node stack to its spill area; rays along the chain (one pending far child per level) force that, with
+    and without the rebuilt hierarchy, closest hit and any hit — results must stay those of the oracle."""
+    from ptmi import native
+    sc = scene_factory("deep_chain")
+    assert sc.bvh_depth >= 33
+    rng = np.random.default_rng(9)
+    n = 60_000
+    c = (sc.tris["v0"].astype(np.float64) + sc.tris["v1"] + sc.tris["v2"]) / 3
+    scale = np.linalg.norm(sc.tris["v1"].astype(np.float64) - sc.tris["v0"], axis=1)
+    pick = rng.integers(0, len(c), n)
+    # a third: rays along the chain from before its start; a third: aimed at a triangle from nearby; a third: random
+    o = np.zeros((n, 3)); d = np.zeros((n, 3))
+    k = n // 3
+    o[:k] = [-1e-12, 0, 0] + rng.normal(size=(k, 3)) * 1e-13; d[:k] = [1, 0, 0] + rng.normal(size=(k, 3)) * rng.choice([0, 1e-3, 0.05], (k, 1))
+    o[k:2 * k] = c[pick[k:2 * k]] + rng.normal(size=(k, 3)) * scale[pick[k:2 * k], None] * 3
+    d[k:2 * k] = c[pick[k:2 * k]] + rng.normal(size=(k, 3)) * scale[pick[k:2 * k], None] * 0.3 - o[k:2 * k]
+    o[2 * k:] = c[pick[2 * k:]] * rng.random((n - 2 * k, 1)) * 2 + rng.normal(size=(n - 2 * k, 3)) * scale[pick[2 * k:], None]
+    d[2 * k:] = rng.normal(size=(n - 2 * k, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o, d = o.astype(np.float32), d.astype(np.float32)
+    t_ref, tri_ref, u_ref, v_ref, _ = oracle.intersect(sc, o, d)
+    assert (t_ref > 0).mean() > 0.15
+    dist = np.where(rng.random(n) < 0.5, -1.0, np.abs(rng.normal(size=n)) * scale[pick] * 4).astype(np.float32)
+    occ_ref = oracle.occluded(sc, o, d, dist)
+    for keep in (0, 1):
+        for trav in (native.TRAVERSAL_GLOBAL, native.TRAVERSAL_AUTO):
+            gpu_ctx.set_options(keep_reference_tree=keep)
+            gpu_ctx.upload_scene(sc)
+            gpu_ctx.set_options(traversal=trav, cull=1)
+            t, tri, u, v = gpu_ctx.debug_intersect(o, d)
+            assert np.array_equal(tri, tri_ref), (keep, trav, int((tri != tri_ref).sum()))
+            assert np.array_equal(t.view(np.uint32), t_ref.view(np.uint32)) and np.array_equal(u.view(np.uint32), u_ref.view(np.uint32))
+            assert np.array_equal(gpu_ctx.debug_occluded(o, d, dist), occ_ref)
+    gpu_ctx.set_options(keep_reference_tree=0, traversal=native.TRAVERSAL_AUTO)

@@ -71,7 +71,10 @@ struct TraverseConfig {
     int stack_entries;      // 14 (node cache only), 16, 32 or 64
     int cull;               // 0/1
     size_t lds_scene_bytes; // LDS variant: bytes of wnodes + tripos
+    uint32_t *spill;        // global variant: per-lane overflow of the node stack, pt_spill_bytes(blocks) bytes
 };
+#define PT_SPILL_ENTRIES 64     /* >= the deepest node stack: upload rejects trees deeper than 62 */
+size_t pt_spill_bytes(int blocks);
 
 // ---- launchers (each enqueues on `s`; grids are persistent, sized by the caller) ----
 void pt_launch_raygen(hipStream_t s, int blocks, const ptmi_camera &cam, DevBand band, uint32_t frame0,

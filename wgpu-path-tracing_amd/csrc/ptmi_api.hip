@@ -51,6 +51,7 @@ struct ptmi_ctx {
     uint64_t *alive = nullptr, *shadowm = nullptr;
     uint32_t *word_off = nullptr, *counts = nullptr;
     unsigned long long *d_stats = nullptr;
+    uint32_t *d_spill = nullptr;          // node-stack overflow of the global traversal variant (allocated on first use)
     uint8_t *d_occ = nullptr;
 
     // statistics
@@ -246,11 +247,13 @@ TraverseConfig traverse_config(const ptmi_ctx *c, bool closest_hit) {
     const int small_stack = c->bvh_depth + 1 <= 15 ? 15 : 16;  // node stack <= depth - 2, plus >= 3 entries for filed leaves
     const bool node_cache = have && c->bvh_depth + 2 <= 16 &&
                             (size_t)c->sc.n_wnodes * 64 + (size_t)small_stack * 1024 * 4 <= kLdsMax / 2;
+    cfg.spill = nullptr;
     if (c->opt.traversal == PTMI_TRAVERSAL_GLOBAL) cfg.variant = PT_VARIANT_GLOBAL;
     else if (closest_hit && node_cache && c->opt.traversal == PTMI_TRAVERSAL_AUTO) {   // any-hit: measured 15 % slower with it
         cfg.variant = PT_VARIANT_LDS_NODES; cfg.stack_entries = small_stack;
     } else if (fits) { cfg.variant = PT_VARIANT_LDS; cfg.stack_entries = lds_stack; }
     else cfg.variant = PT_VARIANT_GLOBAL;
+    if (cfg.variant == PT_VARIANT_GLOBAL) { cfg.stack_entries = 16; cfg.spill = c->d_spill; }   // deeper stacks spill
     return cfg;
 }
 
@@ -307,7 +310,8 @@ int ptmi_create(int device_ordinal, ptmi_ctx **out) {
     c->stream = c->own_stream;
     if (hipMalloc(&c->counts, 80 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(&c->d_stats, kStatsWords * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(c->d_stats, 0, kStatsWords * sizeof(unsigned long long)) != hipSuccess) {
+        hipMemset(c->d_stats, 0, kStatsWords * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(&c->d_spill, pt_spill_bytes(c->n_cu * 8)) != hipSuccess) {                 // 128 MiB on 256 CUs
         ptmi_destroy(c); return fail(nullptr, PTMI_E_HIP, "device allocation failed");
     }
     *out = c;
@@ -323,7 +327,7 @@ int ptmi_destroy(ptmi_ctx *c) {
     free_batch(c);
     dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_atlas); dfree(c->d_wnodes); dfree(c->d_tripos);
     dfree(c->d_fast_wnodes);
-    dfree(c->d_out_own); dfree(c->counts); dfree(c->d_stats);
+    dfree(c->d_out_own); dfree(c->counts); dfree(c->d_stats); dfree(c->d_spill);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return PTMI_OK;

@@ -149,7 +149,10 @@ struct ShadowIO {
         slot = i;                                              // the record's own slot is what finish() needs
         float4 so = S.SO[i], sd = S.SD[i];
         o = xyz(so); d = xyz(sd);
-        tlim = so.w < 0.0f ? -1.0f : so.w - PT_EPS * 2.0f;    // pt.wgsl:394 / :423, :465
+        // pt.wgsl:423, :465: occluded iff a hit is nearer than dist - 2e-6 (negative for a light closer than 2e-6: never
+        // occluded). A directional light (:394) has no distance, any hit occludes, one at t = +inf included: tlim = NaN,
+        // and the tests below are written so that NaN means "no limit" (!(t >= NaN) is true, tl > NaN is false).
+        tlim = so.w < 0.0f ? __builtin_nanf("") : so.w - PT_EPS * 2.0f;
     }
     PT_DEV void finish(uint32_t i, const Hit &, bool occluded) const {
         if (occluded_out) { occluded_out[i] = occluded ? 1 : 0; return; }
@@ -175,9 +178,15 @@ struct ShadowIO {
 // can join whichever stream runs (lane utilisation of VALU instructions 31 % -> 65 %). The tested leaf
 // set is unchanged; only the visiting order differs, and the result is order-independent
 // (min over (t, index)).
-template <int MODE, bool CULL, int STACK, class Mem, class IO>
+// SPILL (global variant): the LDS entries hold only the top of the node stack. When a push finds no room the lane
+// moves its whole LDS node stack to its column of `spill` (entry k of lane g at spill[k * spill_lanes + g], so a wave's
+// accesses coalesce) and goes on with an empty one; when the LDS part runs dry it takes the last 8 spilled entries
+// back. Deep trees then need no deeper LDS stacks — the occupancy of a depth-60 scene is that of a depth-14 one — and
+// the order in which nodes are visited, hence every result, is unchanged.
+template <int MODE, bool CULL, int STACK, bool SPILL, class Mem, class IO>
 PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t count, uint32_t gw,
-                             uint32_t total_waves, uint32_t *stk, int stride) {
+                             uint32_t total_waves, uint32_t *stk, int stride, uint32_t *spill = nullptr,
+                             uint32_t spill_lanes = 0) {
     constexpr bool ANY = MODE == MODE_SHADOW;
     constexpr int NODE_KEEP = ANY ? 2 : 3;
     const uint32_t lane = threadIdx.x & 63u;
@@ -193,6 +202,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
     // of filed leaves grows down from `top` (lp = next free entry); STACK - used = (lp - sp) / stride + 1 entries free
     const lds_u32p bot = (lds_u32p)stk, top = bot + (STACK - 1) * stride;
     lds_u32p sp = bot, lp = top;
+    uint32_t spn = 0;                       // SPILL: entries of this lane in the spill area
     v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), inv = mk3(0, 0, 0);
     float tlim = 0.0f, limit = __builtin_inff();
     Hit best; best.t = __builtin_inff(); best.u = best.v = 0.0f; best.tri = PT_REF_NONE;
@@ -209,8 +219,8 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                 io.fetch(slot, o, d, tlim);
                 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                 best.t = __builtin_inff(); best.u = best.v = 0.0f; best.tri = PT_REF_NONE;
-                sp = bot; lp = top; cur = PT_REF_NONE; tri_i = tri_e = 0u;
-                limit = (ANY && CULL && !(tlim < 0.0f)) ? cull_limit(tlim) : __builtin_inff();
+                sp = bot; lp = top; spn = 0u; cur = PT_REF_NONE; tri_i = tri_e = 0u;
+                limit = (ANY && CULL) ? cull_limit(tlim) : __builtin_inff();      // NaN for a directional light: never culls
                 const bool regular = __builtin_isfinite(inv.x) & __builtin_isfinite(inv.y) & __builtin_isfinite(inv.z) &
                                      (inv.x != 0.0f) & (inv.y != 0.0f) & (inv.z != 0.0f);
                 use_ref = sc.has_fast != 0u && !regular;
@@ -233,7 +243,8 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
         }
         if (act == 0ull && next >= end) break;
 
-        const bool can_node = active & (cur != PT_REF_NONE) & room2(lp, sp, stride);      // two entries free
+        // two entries free (a step files at most two entries) — or, with SPILL, two free once the node entries are moved out
+        const bool can_node = active & (cur != PT_REF_NONE) & ((int)room2(lp, sp, stride) | (int)(SPILL && (sp != bot) & room2(lp, bot, stride)));
         const bool can_tri = active & ((tri_i < tri_e) | (lp != top));
         const uint64_t bn = ballot(can_node), bt = ballot(can_tri);
         const bool run_tri = popc(bt) > popc(bn);
@@ -256,7 +267,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                         const float t = tri_test(xyz(a), xyz(b), xyz(c), o, d, u, v);
                         const bool hit = t > 0.0f;
                         if (ANY) {
-                            occluded = occluded | (hit & ((tlim < 0.0f) | (t < tlim)));
+                            occluded = occluded | (hit & !(t >= tlim));
                         } else {
                             const bool better = hit & ((t < best.t) | ((t == best.t) & (ti < best.tri)));
                             best.t = better ? t : best.t; best.u = better ? u : best.u;
@@ -277,6 +288,10 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
 #pragma unroll
             for (int rep = 0; rep < NODE_STEPS; rep++) {
                 if (cn) {
+                    if (SPILL && !room2(lp, sp, stride)) {              // rare: move the LDS node stack out
+                        for (lds_u32p q = bot; q != sp; q += stride) { spill[(size_t)spn * spill_lanes] = *q; spn++; }
+                        sp = bot;
+                    }
                     float4 a, b, c, r;
                     if (use_ref) {
                         load_node((glb_f4p)sc.ref_wnodes + 4u * (size_t)cur, a, b, c, r);
@@ -297,10 +312,20 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                     else if (il) cur = lref;
                     else if (ir) cur = rref;
                     else if (sp != bot) { sp -= stride; cur = *sp; }
+                    else if (SPILL && spn != 0u) {                      // rare: take the last 8 spilled entries back
+                        // as many as fit under the leaf list while leaving two entries free (at least the one that is popped)
+                        // (lp can sit one entry below bot when filed leaves fill the LDS entries: free = 0)
+                        const int fit = (int)((uint32_t)(uintptr_t)lp - (uint32_t)(uintptr_t)bot) / (stride * 4);   // free - 1
+                        uint32_t n = spn < 8u ? spn : 8u;
+                        n = (int)n < fit ? n : (fit > 1 ? (uint32_t)fit : 1u);
+                        spn -= n;
+                        for (uint32_t j = 0; j + 1u < n; j++) { *sp = spill[(size_t)(spn + j) * spill_lanes]; sp += stride; }
+                        cur = spill[(size_t)(spn + n - 1u) * spill_lanes];
+                    }
                     else cur = PT_REF_NONE;
                 }
                 if (rep + 1 < NODE_STEPS) {
-                    cn = cn & (cur != PT_REF_NONE) & room2(lp, sp, stride);
+                    cn = cn & (cur != PT_REF_NONE) & ((int)room2(lp, sp, stride) | (int)(SPILL && (sp != bot) & room2(lp, bot, stride)));
                     if (popc(ballot(cn)) * NODE_KEEP < popc(bn)) break;
                 }
             }
@@ -316,13 +341,15 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
 constexpr int GBLOCK = 256;
 
 template <int MODE, bool CULL, int STACK, class IO>
-__global__ __launch_bounds__(GBLOCK) void k_trace_global(DevScene sc, IO io, const uint32_t *__restrict__ count_ptr) {
+__global__ __launch_bounds__(GBLOCK) void k_trace_global(DevScene sc, IO io, const uint32_t *__restrict__ count_ptr,
+                                                         uint32_t *__restrict__ spill) {
     __shared__ uint32_t stk[STACK * GBLOCK];
     const uint32_t count = *count_ptr;
     const uint32_t gw = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;       // consecutive groups -> different workgroups
     if (gw * 64u >= count) return;
     GlobalMem m{(glb_f4p)sc.wnodes, (glb_f4p)sc.tripos};
-    trace_wave<MODE, CULL, STACK>(m, sc, io, count, gw, gridDim.x * (GBLOCK / 64), stk + threadIdx.x, GBLOCK);
+    trace_wave<MODE, CULL, STACK, true>(m, sc, io, count, gw, gridDim.x * (GBLOCK / 64), stk + threadIdx.x, GBLOCK,
+                                        spill + (size_t)blockIdx.x * GBLOCK + threadIdx.x, gridDim.x * GBLOCK);
 }
 
 // --------------------------------------------------------------------- LDS ----
@@ -349,7 +376,7 @@ __global__ __launch_bounds__(LBLOCK) void k_trace_lds(DevScene sc, IO io, const 
     if (gw * 64u >= count) return;
     LdsMem<TRIS_IN_LDS> m{(lds_f4p)smem, (lds_f4p)(smem + nw), (glb_f4p)sc.tripos};
     uint32_t *stk = reinterpret_cast<uint32_t *>(smem + nw + nt) + threadIdx.x;
-    trace_wave<MODE, CULL, STACK>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk, LBLOCK);
+    trace_wave<MODE, CULL, STACK, false>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk, LBLOCK);
 }
 
 template <int MODE, bool CULL, int STACK, bool TRIS, class IO>
@@ -367,18 +394,23 @@ void launch_lds(hipStream_t s, int wgs, size_t bytes, const DevScene &sc, const 
     hipLaunchKernelGGL((k_trace_lds<MODE, CULL, STACK, TRIS, IO>), dim3(wgs), dim3(LBLOCK), bytes, s, sc, io, count);
 }
 
-// The persistent grid of the global variant is the workgroups that run at once; what limits them is the LDS the
-// per-lane stacks take (16 / 24 / 32 / 64 entries x 256 lanes x 4 B). Measured (extend, ms per 64 spp, workgroups per CU):
-//   cornell_spheres, 24 entries: 4: 30.1  5: 27.7  6: 25.0  7: 33.0  8: 31.2  12: 25.7   -> 6 = floor(160 KB / 24 KB)
-//   grid_1m,         32 entries: 3: 27.5  4: 23.8  5: 32.5  8: 26.3  16: 32.2           -> 4, although 5 x 32 KB = 160 KB
-// A grid one workgroup per CU too large runs a second, almost empty round (each workgroup carries a full share of
-// the queue), so the count keeps one byte of LDS spare: 8 / 6 / 4 / 2 per CU.
-template <int MODE, bool CULL, int STACK, class IO>
-void launch_global(hipStream_t s, int cus, const DevScene &sc, const IO &io, const uint32_t *count) {
-    constexpr int lds_bytes = STACK * GBLOCK * 4;
-    constexpr int by_lds = (160 * 1024 - 1) / lds_bytes;
-    constexpr int per_cu = by_lds < 1 ? 1 : by_lds < 8 ? by_lds : 8;
-    hipLaunchKernelGGL((k_trace_global<MODE, CULL, STACK, IO>), dim3(per_cu * cus), dim3(GBLOCK), 0, s, sc, io, count);
+// The persistent grid of the global variant is exactly the workgroups that are resident at once: every workgroup
+// carries a full share of the queue, so one more per CU than fit runs a second, almost empty round. Sweep (extend, ms
+// per 64 spp, workgroups per CU; 16 LDS entries per lane + spill area):
+//   cornell_spheres  3: 34.7  4: 30.7  5: 28.6  6: 25.9  7: 33.1  8: 30.8
+//   grid_1m          3: 28.9  4: 24.9  5: 23.7  6: 23.1  7: 28.9  8: 27.1
+// 6 is what the kernel's registers allow (4 waves per workgroup, 6 waves per SIMD); the occupancy query reports it.
+// (Before the stacks could spill, depth-29 grid_1m needed 32 LDS entries per lane: 4 workgroups per CU, 23.8 ms.)
+constexpr int GLOBAL_WGS_MAX = 8;          // what the spill area is sized for
+template <int MODE, bool CULL, class IO>
+void launch_global(hipStream_t s, int cus, const DevScene &sc, const IO &io, const uint32_t *count, uint32_t *spill) {
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace_global<MODE, CULL, 16, IO>, GBLOCK, 0) != hipSuccess || n < 1) n = 6;
+        per_cu = n < GLOBAL_WGS_MAX ? n : GLOBAL_WGS_MAX;
+    }
+    hipLaunchKernelGGL((k_trace_global<MODE, CULL, 16, IO>), dim3(per_cu * cus), dim3(GBLOCK), 0, s, sc, io, count, spill);
 }
 
 template <int MODE, bool CULL, class IO>
@@ -394,14 +426,8 @@ void launch(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene
         const size_t bytes = cfg.lds_scene_bytes + stack_bytes;
         if (cfg.stack_entries <= 16) launch_lds<MODE, CULL, 16, true>(s, cus, bytes, sc, io, count);
         else launch_lds<MODE, CULL, 32, true>(s, cus, bytes, sc, io, count);
-    } else if (cfg.stack_entries <= 16) {
-        launch_global<MODE, CULL, 16>(s, cus, sc, io, count);
-    } else if (cfg.stack_entries <= 24) {
-        launch_global<MODE, CULL, 24>(s, cus, sc, io, count);
-    } else if (cfg.stack_entries <= 32) {
-        launch_global<MODE, CULL, 32>(s, cus, sc, io, count);
     } else {
-        launch_global<MODE, CULL, 64>(s, cus, sc, io, count);
+        launch_global<MODE, CULL>(s, cus, sc, io, count, cfg.spill);
     }
 }
 
@@ -419,4 +445,9 @@ void pt_launch_shadow(hipStream_t s, int blocks, const TraverseConfig &cfg, cons
     ShadowIO io{p, sh, shadow_queue, occ};
     if (cfg.cull) launch<MODE_SHADOW, true>(s, blocks, cfg, sc, io, count);
     else launch<MODE_SHADOW, false>(s, blocks, cfg, sc, io, count);
+}
+
+size_t pt_spill_bytes(int blocks) {
+    const int cus = blocks / 8 > 0 ? blocks / 8 : 1;
+    return (size_t)GLOBAL_WGS_MAX * cus * GBLOCK * PT_SPILL_ENTRIES * sizeof(uint32_t);
 }

@@ -346,8 +346,26 @@ def random_soup(seed, n_tris=400):
     return _finish("random_soup_%d" % seed, [tris, floor], mats, punctual=punctual, atlas=atlas)
 
 
+def deep_chain(n=1000, ratio=1.08):
+    """Triangles whose position and size grow geometrically along +x: the reference builder always cuts the biggest
+    twelfth off, so the BVH is a 35-level chain (root = 1) — deeper than any fixed on-chip stack this library uses —
+    and a ray along the chain keeps one pending far child per level."""
+    k = np.arange(n)
+    x = (ratio ** k - 1.0) * 1e-12
+    s = 0.5 * ratio ** k * 1e-12
+    v = np.zeros((n, 3, 3), np.float64)
+    v[:, 0] = np.stack([x, 0 * x, 0 * x], 1)
+    v[:, 1] = np.stack([x + s, 0 * x, 0.3 * s], 1)
+    v[:, 2] = np.stack([x, s, 0 * x], 1)
+    nrm = np.zeros((n, 3, 3), np.float32)
+    nrm[..., 2] = 1.0
+    tris = _tri_array(v.astype(np.float32), nrm, np.zeros((n, 3, 2), np.float32), np.arange(n) % 2)
+    mats = [_material(_WHITE), _material(_WHITE, emission=(1, 1, 1), strength=4.0)]
+    return _finish("deep_chain", [tris], mats)
+
+
 SCENES = {"cornell": cornell, "cornell_glass": lambda: cornell(glass=True),
-          "cornell_spheres": cornell_spheres, "grid_1m": grid_1m, "feature_box": feature_box}
+          "cornell_spheres": cornell_spheres, "grid_1m": grid_1m, "feature_box": feature_box, "deep_chain": deep_chain}
 
 
 def make(name):
