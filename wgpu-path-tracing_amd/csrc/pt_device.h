@@ -71,6 +71,7 @@ struct TraverseConfig {
     int stack_entries;      // 14 (node cache only), 16, 32 or 64
     int cull;               // 0/1
     size_t lds_scene_bytes; // LDS variant: bytes of wnodes + tripos
+    int wgs_per_cu;         // node cache: 2 (small trees, whole stack in LDS) or 1 (mid-size trees, spilling stacks)
     uint32_t *spill;        // global variant: per-lane overflow of the node stack, pt_spill_bytes(blocks) bytes
 };
 #define PT_SPILL_ENTRIES 64     /* >= the deepest node stack: upload rejects trees deeper than 62 */

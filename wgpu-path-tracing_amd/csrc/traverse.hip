@@ -363,8 +363,9 @@ __global__ __launch_bounds__(GBLOCK) void k_trace_global(DevScene sc, IO io, con
 // triangle and miss the LDS-resident triangles); ptmi_api picks per kernel.
 constexpr int LBLOCK = 1024;
 
-template <int MODE, bool CULL, int STACK, bool TRIS_IN_LDS, class IO>
-__global__ __launch_bounds__(LBLOCK) void k_trace_lds(DevScene sc, IO io, const uint32_t *__restrict__ count_ptr) {
+template <int MODE, bool CULL, int STACK, bool TRIS_IN_LDS, bool SPILL, class IO>
+__global__ __launch_bounds__(LBLOCK) void k_trace_lds(DevScene sc, IO io, const uint32_t *__restrict__ count_ptr,
+                                                      uint32_t *__restrict__ spill) {
     extern __shared__ float4 smem[];
     const uint32_t count = *count_ptr;
     if (blockIdx.x * 64u >= count) return;      // wave 0 owns group blockIdx.x; if that is empty the whole group is idle
@@ -376,22 +377,24 @@ __global__ __launch_bounds__(LBLOCK) void k_trace_lds(DevScene sc, IO io, const 
     if (gw * 64u >= count) return;
     LdsMem<TRIS_IN_LDS> m{(lds_f4p)smem, (lds_f4p)(smem + nw), (glb_f4p)sc.tripos};
     uint32_t *stk = reinterpret_cast<uint32_t *>(smem + nw + nt) + threadIdx.x;
-    trace_wave<MODE, CULL, STACK, false>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk, LBLOCK);
+    trace_wave<MODE, CULL, STACK, SPILL>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk, LBLOCK,
+                                         SPILL ? spill + (size_t)blockIdx.x * LBLOCK + threadIdx.x : nullptr, gridDim.x * LBLOCK);
 }
 
-template <int MODE, bool CULL, int STACK, bool TRIS, class IO>
-void launch_lds(hipStream_t s, int wgs, size_t bytes, const DevScene &sc, const IO &io, const uint32_t *count) {
+template <int MODE, bool CULL, int STACK, bool TRIS, bool SPILL = false, class IO>
+void launch_lds(hipStream_t s, int wgs, size_t bytes, const DevScene &sc, const IO &io, const uint32_t *count,
+                uint32_t *spill = nullptr) {
     // the default dynamic-LDS cap is 64 KB; raise it once per instantiation and device
     static std::atomic<uint64_t> raised{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     const uint64_t bit = 1ull << (dev & 63);
     if (!(raised.load(std::memory_order_relaxed) & bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_lds<MODE, CULL, STACK, TRIS, IO>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_lds<MODE, CULL, STACK, TRIS, SPILL, IO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         raised.fetch_or(bit, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((k_trace_lds<MODE, CULL, STACK, TRIS, IO>), dim3(wgs), dim3(LBLOCK), bytes, s, sc, io, count);
+    hipLaunchKernelGGL((k_trace_lds<MODE, CULL, STACK, TRIS, SPILL, IO>), dim3(wgs), dim3(LBLOCK), bytes, s, sc, io, count, spill);
 }
 
 // The persistent grid of the global variant is exactly the workgroups that are resident at once: every workgroup
@@ -418,7 +421,11 @@ void launch(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene
             const uint32_t *count) {
     const int cus = blocks / 8 > 0 ? blocks / 8 : 1;
     const size_t stack_bytes = (size_t)cfg.stack_entries * LBLOCK * sizeof(uint32_t);
-    if (cfg.variant == PT_VARIANT_LDS_NODES) {                 // node cache, two workgroups per CU
+    if (cfg.variant == PT_VARIANT_LDS_NODES && cfg.wgs_per_cu == 1) {
+        // mid-size trees: all wide nodes in LDS next to 16 stack entries per lane (deeper stacks spill), one workgroup per CU
+        const size_t bytes = (size_t)sc.n_wnodes * 64 + (size_t)16 * LBLOCK * sizeof(uint32_t);
+        launch_lds<MODE, CULL, 16, false, true>(s, cus, bytes, sc, io, count, cfg.spill);
+    } else if (cfg.variant == PT_VARIANT_LDS_NODES) {          // node cache, two workgroups per CU
         const size_t bytes = (size_t)sc.n_wnodes * 64 + stack_bytes;
         if (cfg.stack_entries <= 15) launch_lds<MODE, CULL, 15, false>(s, 2 * cus, bytes, sc, io, count);
         else launch_lds<MODE, CULL, 16, false>(s, 2 * cus, bytes, sc, io, count);
