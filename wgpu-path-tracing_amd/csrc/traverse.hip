@@ -21,9 +21,11 @@
 // max-over-64 / mean = 2.0), which is what this removes.
 //
 // Three memory variants share the body:
-//   global     : wide nodes / triangle images read through L1/L2, per-lane stack in LDS
+//   global     : wide nodes / triangle images read through L1/L2; 16 stack entries per lane in LDS, deeper node
+//                stacks spill to global memory (any depth up to the 62 the upload accepts)
 //   lds        : the whole traversal image staged into LDS once per persistent workgroup
-//   node cache : only the wide nodes staged, so two workgroups share a CU
+//   node cache : only the wide nodes staged — small trees: two workgroups share a CU; mid-size trees: one
+//                workgroup per CU with spilling stacks
 #include "pt_device.h"
 #include "pt_math.h"
 #include <atomic>
