@@ -1,0 +1,22 @@
+import os, sys, time
+ROOT = os.getcwd()
+sys.path.insert(0, os.path.join(ROOT, "wgpu-path-tracing_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from ptmi import layout, native, scenes
+from oracle_lib import Oracle
+oracle, ctx = Oracle(), native.Context(0)
+bad = 0
+for seed in range(8):
+    sc = scenes.random_soup(100 + seed, n_tris=8000 + 9000 * (seed % 4))
+    W, H, frames = 384, 256, 4
+    cam = layout.make_camera(W, H, aperture=0.01 * (seed % 2), focus_distance=2.5, frame_index=seed)
+    t0 = time.time(); ref, ost = oracle.render(sc, cam, frames, max_bounces=8, do_mis=1); tc = time.time() - t0
+    for keep in (0, 1):
+        ctx.set_options(keep_reference_tree=keep); ctx.upload_scene(sc); ctx.resize(W, H)
+        ctx.set_options(max_bounces=8, do_mis=1, frames_per_batch=0, cull=1, traversal=native.TRAVERSAL_AUTO, tile_y0=0, tile_y1=0, tile_parts=0)
+        ctx.reset_stats(); ctx.dispatch(cam, frames); got = ctx.read_output(); st = ctx.stats()
+        diff = (got.view(np.uint32) != ref.view(np.uint32)) & ~(np.isnan(got) & np.isnan(ref))
+        ok = not diff.any() and (st.segments, st.shadow_rays) == (ost.segments, ost.shadow_rays)
+        bad += not ok
+        print(f"seed {seed} tris {len(sc.tris)} depth {sc.bvh_depth} keep {keep} variant {st.traversal_used} segs {st.segments} cpu {tc:.1f}s {'OK' if ok else 'MISMATCH %d' % diff.sum()}", flush=True)
+print("mismatching runs:", bad); sys.exit(1 if bad else 0)
