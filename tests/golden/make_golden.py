@@ -7,7 +7,7 @@ small inputs — regression pins for the oracle itself (other compilers / CPUs /
 versions must reproduce them) and fixed targets for the HIP path. Each file holds the
 complete inputs (scene blobs, camera, rays) next to the expected outputs.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [fixture names]
 """
 import os
 import sys
@@ -26,13 +26,18 @@ CASES = [  # name, scene, W, H, frames, bounces, mis, aperture
     ("cornell_64x48_4spp_mis", "cornell", 64, 48, 4, 8, 1, 0.001),
     ("cornell_64x64_4spp_b4_nomis", "cornell", 64, 64, 4, 4, 0, 0.001),      # BASELINE configs[0] shape, reduced
     ("feature_box_48x48_3spp", "feature_box", 48, 48, 3, 8, 1, 0.05),
+    ("random_soup3_48x48_3spp", "random_soup:3", 48, 48, 3, 8, 1, 0.02),        # degenerate triangles, zero normals, all lobes
+    ("deep_chain_32x32_2spp", "deep_chain", 32, 32, 2, 4, 1, 0.0),              # 58-level BVH (spilling node stacks)
 ]
 
 
 def main():
     orc = Oracle(strict=False)
+    only = set(sys.argv[1:])                  # optional: names of the fixtures to (re)write; default all
     for name, sname, W, H, frames, bounces, mis, ap in CASES:
-        sc = scenes.make(sname)
+        if only and name not in only:
+            continue
+        sc = scenes.random_soup(int(sname.split(":")[1])) if sname.startswith("random_soup:") else scenes.make(sname)
         cam = layout.make_camera(W, H, aperture=ap, focus_distance=2.8)
         out, st = orc.render(sc, cam, frames, max_bounces=bounces, do_mis=mis)
         rng = np.random.default_rng(1234)
@@ -41,6 +46,10 @@ def main():
         d /= np.linalg.norm(d, axis=1, keepdims=True)
         lo, hi = sc.nodes[0]["aabb_min"], sc.nodes[0]["aabb_max"]
         o = (lo + (hi - lo) * rng.random((n, 3))).astype(np.float32)
+        if sname == "deep_chain":             # rays along the chain: every level of the tree keeps a pending far child
+            o = (np.array([-1e-12, 0, 0]) + rng.standard_normal((n, 3)) * 1e-13).astype(np.float32)
+            d = np.array([1.0, 0, 0]) + rng.standard_normal((n, 3)) * rng.choice([0, 1e-3, 0.05], (n, 1))
+            d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
         t, tri, u, v, _ = orc.intersect(sc, o, d)
         dist = (rng.random(n) * 2.0).astype(np.float32)
         dist[::4] = -1

@@ -219,13 +219,14 @@ PT_DEV v4 eval_bsdf(const HitInfo &h, v3 normal, v3 V, v3 L, bool front) {
     return r;
 }
 
-struct LightSample { v3 intensity; v3 wi; float pdf; float dist; };   // dist < 0: directional
+struct LightSample { v3 intensity; v3 wi; float pdf; float dist; bool traced; };   // dist < 0: directional; traced: the
+                                                                                  // reference shoots its shadow ray for this sample
 
 // sampleLight, pt.wgsl:374-489, without its traversal: the occlusion test is the
 // `shadow` kernel's; pdf = 0 means "no record" (the :413-415 early-out).
 PT_DEV LightSample sample_light(const DevScene &sc, uint32_t &rng, v3 hit_pos) {
     LightSample ls;
-    ls.intensity = mk3(0.0f, 0.0f, 0.0f); ls.wi = mk3(0.0f, 0.0f, 0.0f); ls.pdf = 0.0f; ls.dist = -1.0f;
+    ls.intensity = mk3(0.0f, 0.0f, 0.0f); ls.wi = mk3(0.0f, 0.0f, 0.0f); ls.pdf = 0.0f; ls.dist = -1.0f; ls.traced = false;
     const uint32_t nl = sc.n_lights;
     const ptmi_light lt = sc.lights[rng_int(rng, 0u, nl - 1u)];
     const float inv_n = 1.0f / (float)nl;
@@ -234,6 +235,7 @@ PT_DEV LightSample sample_light(const DevScene &sc, uint32_t &rng, v3 hit_pos) {
         ls.intensity = scale3(ld3(lt.color), lt.intensity);
         ls.pdf = inv_n * 1000.0f;
         ls.dist = -1.0f;
+        ls.traced = true;
     } else if (lt.light_type == PTMI_LIGHT_POINT) {
         v3 to_l = sub3(ld3(lt.position), hit_pos);
         float dist = length3(to_l);
@@ -243,6 +245,7 @@ PT_DEV LightSample sample_light(const DevScene &sc, uint32_t &rng, v3 hit_pos) {
         ls.intensity = scale3(scale3(ld3(lt.color), lt.intensity), att);
         ls.pdf = inv_n * 10000.0f;
         ls.dist = dist;
+        ls.traced = true;
     } else if (lt.light_type == PTMI_LIGHT_EMISSIVE) {
         ptmi_triangle T;
         if (lt.triangle_index < sc.n_tris) T = sc.tris[lt.triangle_index];
@@ -264,6 +267,7 @@ PT_DEV LightSample sample_light(const DevScene &sc, uint32_t &rng, v3 hit_pos) {
         ls.intensity = scale3(ld3(lt.color), lt.intensity);
         ls.wi = wi;
         ls.dist = dist;
+        ls.traced = true;
     }
     return ls;
 }
@@ -317,7 +321,9 @@ __global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const
                             } else {
                                 skipped = true;
                             }
-                        }
+                        } else if (ls.traced) {
+                            skipped = true;         // the reference traces this sample (pt.wgsl:392/421/463) and then drops it:
+                        }                           // its pdf is not > 0 (underflow, 0 * inf); counted, nothing to add
                     }
                     v3 dir = sample_bsdf(rng, hit, rd, hit.is_front);         // pt.wgsl:680
                     v4 ev = eval_bsdf(hit, hit.normal, neg3(normalize3(rd)), dir, hit.is_front);
