@@ -1,31 +1,42 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of the MI355X wavefront path tracer.
+"""bench.py — benchmark of the MI355X wavefront path tracer on BASELINE.json's configurations.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py [--config {0,1,2,3,4}] --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): synthetic Cornell box, 1920x1080, 8 bounces, MIS on.
-One step = one ptmi_dispatch of --frames-per-step frames (default 32, traced as one wavefront
-batch of 66 M paths) over the rank's rows; the default K = 2 steps therefore render exactly the
-64 spp of configs[1]. Scene and output
-live in HBM before the timed region starts (the C ABI copies host blobs at upload).
+--config selects one of BASELINE.json's `configs` (default 1, the configuration the metric is quoted on):
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling over pixel rows —
-the same view at N times the pixels (1920x1080, 2720x1528, 3840x2160, 5424x3040: same aspect,
-so the same mix of cheap and expensive pixels per rank), rank r renders the 4-row strips
-r, r + N, ... with no data-path collective (pixels and RNG streams are independent,
-pt.wgsl:719, :753-761); after the last step the strips are gathered to rank 0 with ONE RCCL
-gather, inside the timed region. value = all ranks' path segments / max-over-ranks time.
+    0  Cornell,            256x256,  16 spp, 4 bounces, MIS off   (configs[0]; on the GPU here — the reference has no CPU path)
+    1  Cornell,          1920x1080,  64 spp, 8 bounces, MIS on    (configs[1])
+    2  Cornell + spheres, 1920x1080, 512 spp, textured PBR        (configs[2])
+    3  1 M-triangle grid, 1920x1080,  64 spp                      (configs[3]; the only scene that reaches the memory side)
+    4  Cornell,          3840x2160, 256 spp, depth of field on (aperture 0.05, focus 2.8)  (configs[4])
 
-Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel (closest-hit
-traversal `extend`) against HBM: algorithmic bytes per ray = 32 (origin+direction
-float4 pair) + 4 (queue index) + 16 (hit record) = 52 B, launch durations
-from HIP events recorded by the library on its own stream around every extend launch.
-`cpu_baseline` times the CPU oracle (oracle/, a restatement — the reference has no CPU
-path) on a bounded crop of the same workload.
+One step = one ptmi_dispatch of --frames-per-step frames (default 32, traced as wavefront batches of up to 64 Mi
+paths) over the rank's rows; K defaults to spp / frames-per-step, so the default run renders exactly the config's
+spp. Scene and output live in HBM before the timed region starts (the C ABI copies host blobs at upload).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU) shards pixel rows, with no data-path collective (pixels
+and RNG streams are independent, pt.wgsl:719, :753-761); after the last step the strips are gathered to rank 0 with
+ONE RCCL gather, inside the timed region. value = all ranks' path segments / max-over-ranks time.
+  configs 0-3: WEAK scaling — the same view at N times the pixels (1920x1080, 2720x1528, 3840x2160, 5424x3040: same
+               aspect, so the same mix of cheap and expensive pixels per rank).
+  config 4:    STRONG scaling — the 3840x2160 frame is fixed and split over the ranks (BASELINE.json: "pixel-tile shard
+               across 8x MI355X with RCCL gather").
+Rank r renders the strips r, r + N, ... (4 rows each, fewer when the frame height is not a whole number of such rounds: 3 for 2160 rows over 8 ranks).
+
+Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel (closest-hit traversal `extend`) against HBM:
+algorithmic bytes per ray = 32 (origin+direction float4 pair) + 4 (queue index) + 16 (hit record) = 52 B (DESIGN.md
+§5), launch durations from HIP events recorded by the library on its own stream around every launch
+(`--timing 3`: every kernel, so `kernel_ms_rank0` adds up to `gpu_ms_rank0`); `roofline.kernels` carries the same
+figures for shade and shadow. `roofline.traffic` replays the committed rocprofv3 counter passes of the same command
+(profiles/<tag>_cfgN_pmc.json, with the commit that made them) — counters cannot be read from inside an un-profiled run.
+`cpu_baseline` times the CPU oracle (oracle/, a restatement — the reference has no CPU path) on a bounded sample of
+the same workload.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,8 +44,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "wgpu-path-tracing_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-EXTEND_BYTES_PER_RAY = 32 + 4 + 16
-HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
+EXTEND_BYTES_PER_RAY = 32 + 4 + 16      # queue 4 + O,D 32 read, hit 16 written
+SHADOW_BYTES_PER_RAY = 4 + 48 + 32      # index 4 + record 48 read, radiance RMW 32 (unoccluded)
+HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
+PROFILE_TAG = "r02"                     # profiles/<tag>_cfgN_*.json are the counter passes replayed in `roofline`
+
+CONFIGS = {
+    0: dict(scene="cornell", width=256, height=256, spp=16, fps=16, bounces=4, mis=0, aperture=0.001, focus=5.0,
+            scaling="weak", name="configs[0]"),
+    1: dict(scene="cornell", width=1920, height=1080, spp=64, fps=32, bounces=8, mis=1, aperture=0.001, focus=5.0,
+            scaling="weak", name="configs[1]"),
+    2: dict(scene="cornell_spheres", width=1920, height=1080, spp=512, fps=32, bounces=8, mis=1, aperture=0.001, focus=5.0,
+            scaling="weak", name="configs[2]"),
+    3: dict(scene="grid_1m", width=1920, height=1080, spp=64, fps=32, bounces=8, mis=1, aperture=0.001, focus=5.0,
+            scaling="weak", name="configs[3]"),
+    4: dict(scene="cornell", width=3840, height=2160, spp=256, fps=32, bounces=8, mis=1, aperture=0.05, focus=2.8,
+            scaling="strong", name="configs[4]"),
+}
+
+
+def shade_bytes_per_segment(do_mis, p_record, bounce0_share):
+    """queue 4 + hit 16 + O,D,T 48 read, O,D,T 48 written (survivors; priced for every segment), ballots 1/4,
+    + 48 per emitted shadow record; bounce 0 reads neither a queue nor a stored throughput."""
+    b = 4 + 16 + 48 + 48 + 0.25 + (48 * p_record if do_mis else 0.0)
+    return b - bounce0_share * (4 + 16)
 
 
 def pipeline_bytes_per_segment(do_mis, mean_len):
@@ -48,39 +81,43 @@ def pipeline_bytes_per_segment(do_mis, mean_len):
     return seg + (48 + 48 - 12 - 16) / max(mean_len, 1e-9)
 
 
-def pmc_traffic(default_workload):
-    """HBM bytes per extend launch from the committed rocprofv3 PMC passes of this exact command
-    (profiles/r01_bench_n1_pmc.json: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs, KB per
-    launch; gfx950 tallies wide reads at half: traffic = 2*FETCH_SIZE + WRITE_SIZE). None when the
-    workload differs from the profiled one — counters cannot be read from inside the timed run."""
-    path = os.path.join(ROOT, "profiles", "r01_bench_n1_pmc.json")
-    if not default_workload or not os.path.exists(path):
+def _git_commit_of(path):
+    try:
+        out = subprocess.run(["git", "log", "-n", "1", "--format=%h", "--", path], cwd=ROOT, capture_output=True,
+                             text=True, timeout=10).stdout.strip()
+        return out or None
+    except Exception:
         return None
+
+
+def profile_path(config, kind):
+    return os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_cfg{config}_{kind}.json")
+
+
+def pmc_traffic(config, is_profiled_workload):
+    """HBM bytes per launch of the traversal and shade kernels from the committed rocprofv3 PMC passes of this exact
+    command (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs, KB per launch; gfx950 tallies wide reads at half:
+    traffic = 2*FETCH_SIZE + WRITE_SIZE). {} when the workload differs from the profiled one."""
+    path = profile_path(config, "pmc")
+    if not is_profiled_workload or not os.path.exists(path):
+        return {}, None
     d = json.load(open(path))
-    try:
-        f = d["FETCH_SIZE"]["k_trace_lds/extend"]["avg_KB_per_launch"]
-        w = d["WRITE_SIZE"]["k_trace_lds/extend"]["avg_KB_per_launch"]
-    except KeyError:
-        return None
-    return int((2 * f + w) * 1024)
+    out = {}
+    for label, keys in (("extend", ("k_trace_lds/extend", "k_trace_global/extend")),
+                        ("shadow", ("k_trace_lds/shadow", "k_trace_global/shadow")), ("shade", ("k_shade",))):
+        f = w = 0.0
+        for k in keys:          # a config uses one variant per kernel; a missing key contributes nothing
+            f += d.get("FETCH_SIZE", {}).get(k, {}).get("avg_KB_per_launch", 0.0) * d.get("FETCH_SIZE", {}).get(k, {}).get("launches", 0)
+            w += d.get("WRITE_SIZE", {}).get(k, {}).get("avg_KB_per_launch", 0.0) * d.get("WRITE_SIZE", {}).get(k, {}).get("launches", 0)
+        n = sum(d.get("FETCH_SIZE", {}).get(k, {}).get("launches", 0) for k in keys)
+        if n:
+            out[label] = int((2 * f + w) / n * 1024)
+    src = {"file": os.path.relpath(path, ROOT), "file_commit": _git_commit_of(path), "code_commit": d.get("_code_commit"),
+           "formula": "2*FETCH_SIZE + WRITE_SIZE, bytes per launch (mean over the profiled run's launches)"}
+    return out, src
 
 
-def valu_issue(avg_launch_ms, default_workload):
-    """SIMD cycles per VALU wave-instruction of the extend kernel: instructions per launch from the committed
-    rocprofv3 --pmc SQ_INSTS_VALU pass (profiles/r01_bench_n1_valu.json), duration measured live."""
-    path = os.path.join(ROOT, "profiles", "r01_bench_n1_valu.json")
-    if not default_workload or not os.path.exists(path) or not avg_launch_ms:
-        return None
-    try:
-        n = json.load(open(path))["SQ_INSTS_VALU"]["k_trace_lds/extend"]["avg_per_launch"]
-    except KeyError:
-        return None
-    return {"wave_instructions_per_launch": int(n),
-            "simd_cycles_per_instruction": round(avg_launch_ms * 1e-3 * 2.4e9 * 1024 / n, 3),
-            "microbenchmark_cycles_per_instruction": 3.0}
-
-
-def cpu_baseline(scene, width, height, bounces, mis, threads, target_s=12.0):
+def cpu_baseline(scene, cam_kw, width, height, bounces, mis, threads, target_s=12.0):
     """Oracle on whole frames of the same camera: 1 calibration frame, then as many frames as
     fit in about target_s seconds (at most the 64 of the workload)."""
     from oracle_lib import Oracle
@@ -88,10 +125,10 @@ def cpu_baseline(scene, width, height, bounces, mis, threads, target_s=12.0):
     import numpy as np
     orc = Oracle(strict=False)
     out = np.zeros((height, width, 4), np.float32)
-    _, st0 = orc.render(scene, layout.make_camera(width, height), 1, max_bounces=bounces, do_mis=mis, out=out,
+    _, st0 = orc.render(scene, layout.make_camera(width, height, **cam_kw), 1, max_bounces=bounces, do_mis=mis, out=out,
                         threads=threads)
     frames = int(max(1, min(63, target_s / max(st0.seconds, 1e-3))))
-    _, st = orc.render(scene, layout.make_camera(width, height, frame_index=1), frames, max_bounces=bounces,
+    _, st = orc.render(scene, layout.make_camera(width, height, frame_index=1, **cam_kw), frames, max_bounces=bounces,
                        do_mis=mis, out=out, threads=threads)
     return {
         "value": round(st.segments / st.seconds / 1e6, 4), "unit": "Msamples/s", "cores": int(st.threads),
@@ -103,26 +140,45 @@ def cpu_baseline(scene, width, height, bounces, mis, threads, target_s=12.0):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None, help="default: the config's spp / frames-per-step")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames-per-step", type=int, default=32)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080, help="rows per GPU")
-    ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--frames-per-step", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None, help="rows per GPU (weak scaling) or of the whole frame (config 4)")
+    ap.add_argument("--bounces", type=int, default=None)
     ap.add_argument("--no-mis", action="store_true")
-    ap.add_argument("--scene", default="cornell")
+    ap.add_argument("--scene", default=None)
+    ap.add_argument("--aperture", type=float, default=None)
+    ap.add_argument("--focus-distance", type=float, default=None)
     ap.add_argument("--frames-per-batch", type=int, default=0)
     ap.add_argument("--traversal", default="auto", choices=["auto", "global", "lds"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--perf-mode", type=int, default=0, help="library option perf_mode (0 = parity arithmetic, the headline)")
+    ap.add_argument("--sort", type=int, default=None, help="library option ray_sort (default: the library's)")
     ap.add_argument("--keep-reference-tree", action="store_true",
                     help="walk the BVH exactly as uploaded instead of the hierarchy rebuilt over its leaves")
     ap.add_argument("--rehearse", action="store_true",
-                    help="dry run of the N>1 path on ONE GPU: every rank uses device 0, gloo backend, bands gathered "
+                    help="dry run of the N>1 path on ONE GPU: every rank uses device 0, gloo backend, strips gathered "
                          "through host memory, rank 0 checks the gathered frame bit for bit against its own unsharded "
                          "render. Not a benchmark.")
-    ap.add_argument("--timing", type=int, default=2, help="library HIP-event timing level (2 = every extend launch, 3 = every kernel)")
+    ap.add_argument("--timing", type=int, default=3, help="library HIP-event timing level (2 = every extend launch, 3 = every kernel)")
     args = ap.parse_args()
+
+    cfg = dict(CONFIGS[args.config])
+    overridden = []
+    for key, val in (("scene", args.scene), ("width", args.width), ("height", args.height), ("bounces", args.bounces),
+                     ("fps", args.frames_per_step), ("aperture", args.aperture), ("focus", args.focus_distance)):
+        if val is not None and val != cfg[key]:
+            cfg[key] = val
+            overridden.append(key)
+    if args.no_mis and cfg["mis"]:
+        cfg["mis"] = 0
+        overridden.append("mis")
+    fps = cfg["fps"]
+    steps = args.steps if args.steps is not None else max(1, cfg["spp"] // fps)
+    spp = steps * fps
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -149,16 +205,22 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    mis = 0 if args.no_mis else 1
-    # Weak scaling: the SAME view at `world` times the pixels (1920x1080 -> 2720x1528 -> 3840x2160 -> 5424x3040), so
-    # the mix of cheap and expensive pixels does not change with N; rank r renders the 4-row strips r, r + N, ...
-    # (an even sample of the picture: no rank is stuck with the expensive rows), gathered once at the end.
-    W, H = shard.weak_frame(args.width, args.height, world)
-    scene = scenes.make(args.scene)
+    mis = cfg["mis"]
+    strong = cfg["scaling"] == "strong"
+    if strong:
+        W, H = cfg["width"], cfg["height"]                     # the frame is fixed; ranks split it
+    else:
+        # the SAME view at `world` times the pixels, so the mix of cheap and expensive pixels does not change with N
+        W, H = shard.weak_frame(cfg["width"], cfg["height"], world)
+    strip = shard.strip_rows_for(H, world)
+    cam_kw = dict(aperture=cfg["aperture"], focus_distance=cfg["focus"])
+    scene = scenes.make(cfg["scene"])
 
     ctx = native.Context(local_rank)
     ctx.set_options(keep_reference_tree=int(args.keep_reference_tree))
+    t_up = time.perf_counter()
     ctx.upload_scene(scene)
+    upload_wall_ms = (time.perf_counter() - t_up) * 1e3
     ctx.resize(W, H)
     frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")       # binding 0, owned by the caller
     ctx.bind_output_device(frame.data_ptr(), frame.numel() * 4)
@@ -169,26 +231,30 @@ def main():
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
     trav = {"auto": native.TRAVERSAL_AUTO, "global": native.TRAVERSAL_GLOBAL, "lds": native.TRAVERSAL_LDS}[args.traversal]
-    ctx.set_options(max_bounces=args.bounces, do_mis=mis, frames_per_batch=args.frames_per_batch, traversal=trav, cull=1,
-                    timing=args.timing, **shard.strip_options(world, rank))
+    extra = {}
+    if args.perf_mode:
+        extra["perf_mode"] = args.perf_mode
+    if args.sort is not None:
+        extra["ray_sort"] = args.sort
+    ctx.set_options(max_bounces=cfg["bounces"], do_mis=mis, frames_per_batch=args.frames_per_batch, traversal=trav, cull=1,
+                    timing=args.timing, **extra, **shard.strip_options(world, rank, strip))
 
-    fps = args.frames_per_step
     frame_index = 0
 
     def step():
         nonlocal frame_index
-        ctx.dispatch(layout.make_camera(W, H, frame_index=frame_index), fps)
+        ctx.dispatch(layout.make_camera(W, H, frame_index=frame_index, **cam_kw), fps)
         frame_index += fps
 
     def gather():
-        # the bands accumulate locally; ONE gather assembles the frame after the last frame
+        # the strips accumulate locally; ONE gather assembles the frame after the last frame
         if world > 1 and args.rehearse:
             host = frame.cpu()
-            shard.gather_strips(dist, host, world, rank)
+            shard.gather_strips(dist, host, world, rank, strip)
             if rank == 0:
                 frame.copy_(host)
         elif world > 1:
-            shard.gather_strips(dist, frame, world, rank)
+            shard.gather_strips(dist, frame, world, rank, strip)
 
     def fence():
         if world > 1:
@@ -201,7 +267,7 @@ def main():
     fence()
     ctx.reset_stats()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     gather()
     fence()
@@ -214,8 +280,8 @@ def main():
         gathered = frame.cpu().numpy().copy()
         ctx.set_options(tile_y0=0, tile_y1=0, tile_parts=0, tile_part=0, timing=0)
         frame.zero_()
-        for k in range(args.warmup + args.steps):
-            ctx.dispatch(layout.make_camera(W, H, frame_index=k * fps), fps)
+        for k in range(args.warmup + steps):
+            ctx.dispatch(layout.make_camera(W, H, frame_index=k * fps, **cam_kw), fps)
         torch.cuda.synchronize()
         rehearsal_ok = bool(np.array_equal(gathered.view(np.uint32), frame.cpu().numpy().view(np.uint32)))
     t = torch.tensor([dt, float(st.segments), float(st.shadow_rays), float(st.paths)], dtype=torch.float64,
@@ -230,50 +296,79 @@ def main():
     if rank == 0:
         mean_len = segments / paths
         msamples = segments / dt / 1e6
-        ext_ms = st.extend_ms / max(st.extend_launches, 1)
-        ext_gbs = (st.segments * EXTEND_BYTES_PER_RAY / 1e9) / (st.extend_ms / 1e3) if st.extend_ms > 0 else None
         b_seg = pipeline_bytes_per_segment(mis, mean_len)
+        is_profiled = (not overridden and world == 1 and args.traversal == "auto" and args.steps is None
+                       and not args.perf_mode and args.sort is None and not args.keep_reference_tree
+                       and args.frames_per_batch == 0)
+        traffic, traffic_src = pmc_traffic(args.config, is_profiled)
+
+        def kernel_entry(label, name, ms, launches, units, bytes_per_unit):
+            if not launches or ms <= 0:
+                return None
+            gbs = units * bytes_per_unit / 1e9 / (ms / 1e3)
+            e = {"kernel": name, "bytes_per_unit": round(bytes_per_unit, 2), "units_per_launch": round(units / launches, 1),
+                 "algorithmic_bytes_per_launch": int(units * bytes_per_unit / launches),
+                 "avg_launch_ms": round(ms / launches, 4), "launches": int(launches),
+                 "achieved": round(gbs, 3), "frac": round(gbs / HBM_PEAK_GBS, 6), "traffic": traffic.get(label)}
+            if traffic.get(label):
+                e["traffic_gbs"] = round(traffic[label] / 1e9 / (ms / launches / 1e3), 3)
+                e["traffic_frac"] = round(e["traffic_gbs"] / HBM_PEAK_GBS, 6)
+            return e
+
+        p_record = st.shadow_traced / max(st.segments, 1)
+        b0_share = (st.segments_by_bounce[0] / st.segments) if st.segments else 0.0
+        ext = kernel_entry("extend", "extend (closest-hit BVH traversal)", st.extend_ms, st.extend_launches, st.segments,
+                           EXTEND_BYTES_PER_RAY)
+        shd = kernel_entry("shade", "shade (material, next-event record, BSDF sample, Russian roulette)", st.shade_ms,
+                           st.shade_launches, st.segments, shade_bytes_per_segment(mis, p_record, b0_share))
+        shw = kernel_entry("shadow", "shadow (any-hit visibility of the next-event record)", st.shadow_ms, st.shadow_launches,
+                           st.shadow_traced, SHADOW_BYTES_PER_RAY)
+        kernel_ms = {"extend": st.extend_ms, "shade": st.shade_ms, "shadow": st.shadow_ms, "raygen": st.raygen_ms,
+                     "compact": st.compact_ms, "accumulate": st.accumulate_ms}
+        par = f"{strip}-row strips x{world}"
         out = {
             "metric": "Msamples/s (rays x bounces / s)", "value": round(msamples, 3), "unit": "Msamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": cfg["scaling"],
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"{args.scene} {args.width}x{args.height} pixels per GPU, {args.steps * fps} spp, {args.bounces} bounces, "
-                            f"MIS {'on' if mis else 'off'} (BASELINE.json configs[1]); frame {W}x{H}",
+                "workload": f"BASELINE.json {cfg['name']}: {cfg['scene']} "
+                            + (f"{W}x{H} frame split over {world} GPU(s)" if strong else f"{cfg['width']}x{cfg['height']} pixels per GPU (frame {W}x{H})")
+                            + f", {spp} spp, {cfg['bounces']} bounces, MIS {'on' if mis else 'off'}, aperture {cfg['aperture']:g}, "
+                              f"focus {cfg['focus']:g}" + (f"; overridden: {','.join(overridden)}" if overridden else ""),
+                "config_index": args.config,
                 "frames_per_step": fps, "frames_per_batch": int(st.frames_per_batch_used),
                 "traversal": "lds" if st.traversal_used == native.TRAVERSAL_LDS else "global",
-                "triangles": int(len(scene.tris)), "bvh_nodes": int(len(scene.nodes)), "parallelism": f"{shard.STRIP_ROWS}-row strips x{world}",
+                "triangles": int(len(scene.tris)), "bvh_nodes": int(len(scene.nodes)), "parallelism": par,
+                **({"perf_mode": args.perf_mode} if args.perf_mode else {}),
             },
             **({"rehearsal": {"sharded_equals_unsharded_bitwise": rehearsal_ok, "backend": "gloo", "note": "all ranks on one GPU; not a benchmark"}} if args.rehearse else {}),
             "segments": int(segments), "shadow_rays": int(shadow_rays), "paths": int(paths),
+            "shadow_traced_rank0": int(st.shadow_traced),
             "mean_path_length": round(mean_len, 4),
-            "nominal_msamples": round(paths * args.bounces / dt / 1e6, 3),
+            "nominal_msamples": round(paths * cfg["bounces"] / dt / 1e6, 3),
             "gpu_ms_rank0": round(st.gpu_ms, 3),
-            "kernel_ms_rank0": {"extend": round(st.extend_ms, 3), "shade": round(st.shade_ms, 3),
-                                "shadow": round(st.shadow_ms, 3)},
+            "kernel_ms_rank0": {k: round(v, 3) for k, v in kernel_ms.items()},
+            "kernel_ms_sum_over_gpu_ms": round(sum(kernel_ms.values()) / st.gpu_ms, 4) if st.gpu_ms > 0 else None,
+            "upload_ms_rank0": {"wall": round(upload_wall_ms, 2), "library": round(st.upload_ms, 2),
+                                "rebuilt_hierarchy": round(st.upload_tree_ms, 2), "copies": round(st.upload_copy_ms, 2)},
             "roofline": {
-                "bound": "hbm", "kernel": "extend (closest-hit BVH traversal)",
-                "achieved": None if ext_gbs is None else round(ext_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": None if ext_gbs is None else round(ext_gbs / HBM_PEAK_GBS, 6),
-                "traffic": pmc_traffic(args.scene == "cornell" and W == 1920 and args.height == 1080 and fps == 32
-                                       and world == 1 and args.traversal == "auto" and mis and args.bounces == 8),
-                "traffic_note": "bytes per extend launch, 2*FETCH_SIZE+WRITE_SIZE from profiles/r01_bench_n1_pmc.json",
-                "algorithmic_bytes_per_launch": int(st.segments * EXTEND_BYTES_PER_RAY / max(st.extend_launches, 1)),
-                "bytes_per_unit": EXTEND_BYTES_PER_RAY, "units_per_launch": round(st.segments / max(st.extend_launches, 1), 1),
-                "avg_launch_ms": round(ext_ms, 4), "launches": int(st.extend_launches),
+                "bound": "hbm", "kernel": ext["kernel"] if ext else None,
+                "achieved": ext["achieved"] if ext else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ext["frac"] if ext else None,
+                "traffic": ext["traffic"] if ext else None,
+                "traffic_source": traffic_src,
+                **({k: ext[k] for k in ("algorithmic_bytes_per_launch", "bytes_per_unit", "units_per_launch", "avg_launch_ms",
+                                        "launches")} if ext else {}),
+                **({k: ext[k] for k in ("traffic_gbs", "traffic_frac") if k in ext} if ext else {}),
+                "kernels": {k: v for k, v in (("extend", ext), ("shade", shd), ("shadow", shw)) if v},
                 "pipeline_bytes_per_segment": round(b_seg, 1),
                 "pipeline_achieved": round(msamples * 1e6 * b_seg / 1e9, 3),
                 "pipeline_frac": round(msamples * 1e6 * b_seg / 1e9 / HBM_PEAK_GBS, 6),
-                # why frac is low: the kernel saturates the vector ALUs, not HBM (scene in LDS / L2). VALU instructions per
-                # launch from the committed SQ_INSTS_VALU pass of this command; cycles at the nominal 2.4 GHz over 1024 SIMDs
-                # (a VALU microbenchmark, tools/ubench/pk.hip, issues one per 3.0 cycles per SIMD at this occupancy)
-                "valu": valu_issue(ext_ms, args.scene == "cornell" and W == 1920 and args.height == 1080 and fps == 32
-                                   and world == 1 and args.traversal == "auto" and mis and args.bounces == 8),
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, W, H, args.bounces, mis, min(16, os.cpu_count() or 1))
+            out["cpu_baseline"] = cpu_baseline(scene, cam_kw, W, H, cfg["bounces"], mis, min(16, os.cpu_count() or 1))
         print(json.dumps(out), flush=True)
 
     ctx.close()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PTMI_ABI_VERSION 1
+#define PTMI_ABI_VERSION 2
 
 enum {
     PTMI_OK = 0,
@@ -54,7 +54,8 @@ typedef struct ptmi_options {
     uint32_t cull;              /* 1 (default): ordered traversal with conservative distance cull;
                                    0: every box-overlapping leaf is tested, as pt.wgsl:248-291 does */
     uint32_t timing;            /* 0: none; 1: HIP events around each dispatch (gpu_ms); 2: also around every
-                                   extend launch (extend_ms); 3: also around every shade and shadow launch.
+                                   extend launch (extend_ms); 3: around every kernel launch (extend, shade, shadow,
+                                   raygen, compaction, accumulate — the per-kernel times then add up to gpu_ms).
                                    Each event pair costs a few microseconds of stream time. */
     uint32_t keep_reference_tree; /* read by ptmi_upload_scene. 0 (default): when every node box of the uploaded BVH contains
                                    its children's boxes, traversal walks a SAH hierarchy rebuilt over the SAME leaves (same
@@ -63,7 +64,14 @@ typedef struct ptmi_options {
                                    rows [tile_y0, tile_y1), the strips of tile_strip rows (0 -> 1) numbered tile_part,
                                    tile_part + N, ... — N contexts with tile_part = 0..N-1 cover the range exactly once, each
                                    with an even sample of the picture. 0 / 1 = all rows of the range (default) */
-    uint32_t reserved[4];
+    uint32_t perf_mode;         /* 0 (default): the parity arithmetic of DESIGN.md §3 — results equal the oracle's bit for bit.
+                                   1: `shade` may use the device's fast reciprocal / reciprocal square root / square root
+                                   (1 ulp) instead of the correctly rounded forms. Same RNG streams and control flow; radiance
+                                   agrees statistically (tests/test_gpu_perf_mode.py), not bit for bit. Never the headline. */
+    uint32_t ray_sort;          /* 0: queues keep ascending path order; 1: within each compaction tile (16384 slots) surviving rays
+                                   are grouped by direction octant before the next traversal (coherent waves; results unchanged);
+                                   2 = library default (currently the measured better of the two) */
+    uint32_t reserved[2];
 } ptmi_options;
 
 typedef struct ptmi_stats {
@@ -84,6 +92,13 @@ typedef struct ptmi_stats {
     uint32_t traversal_used;    /* PTMI_TRAVERSAL_GLOBAL or _LDS */
     uint32_t frames_per_batch_used;
     uint32_t reserved;
+    /* ABI 2 */
+    uint64_t shadow_traced;     /* shadow records the any-hit kernel actually traced (shadow_rays minus the zero-contribution ones) */
+    uint64_t shade_launches, shadow_launches;
+    double   raygen_ms, compact_ms, accumulate_ms;   /* timing >= 3 */
+    double   upload_ms;         /* wall time of the last ptmi_upload_scene, and its parts: validation + traversal image, */
+    double   upload_tree_ms;    /* ... the hierarchy rebuilt over the uploaded leaves, */
+    double   upload_copy_ms;    /* ... host-to-device copies */
 } ptmi_stats;
 
 /* ---- lifetime ----------------------------------------------------------- */
@@ -130,9 +145,12 @@ int ptmi_set_stream(ptmi_ctx *ctx, void *hip_stream);
 
 /* ---- presentation (the reference's blit pass, src/shader/blit.wgsl:43-155; renderer.ts:434-449) ---- */
 /* Tone-maps the output buffer (exposure 2^1, AgX, gamma 1/2.2) into a width*height canvas, row 0 = top.
- * dst_rgba_f32 (width*height*4 floats, alpha 1) and/or dst_rgba8 (width*height*4 bytes); either may be NULL.
+ * dst_rgba_f32 (n_floats must be width*height*4, alpha 1) and/or dst_rgba8 (n_bytes must be width*height*4);
+ * either pointer may be NULL (its count is then ignored). A wrong count is PTMI_E_INVALID: nothing is written.
  * Synchronises. Uses the device's log2/pow: compared with a tolerance, not bit for bit. */
-int ptmi_blit(ptmi_ctx *ctx, float *dst_rgba_f32, uint8_t *dst_rgba8);
+int ptmi_blit(ptmi_ctx *ctx, float *dst_rgba_f32, size_t n_floats, uint8_t *dst_rgba8, size_t n_bytes);
+/* Size of the output buffer as last set by ptmi_resize (0 x 0 before). */
+int ptmi_get_size(const ptmi_ctx *ctx, uint32_t *width, uint32_t *height);
 
 /* ---- statistics ----------------------------------------------------------- */
 int ptmi_get_stats(ptmi_ctx *ctx, ptmi_stats *out);           /* synchronises */

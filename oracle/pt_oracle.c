@@ -18,8 +18,9 @@
  *       WGSL operator, never contracted (-ffp-contract=off).
  *   PT_STRICT=1 (libpt_oracle_strict.so) the literal transcription: every WGSL
  *       '/' is an IEEE division, no fused multiply-add anywhere, libm
- *       sinf/cosf/tanf/powf. tests/test_oracle_strict.py shows the two builds
- *       agree to Monte-Carlo-branch-flip level.
+ *       sinf/cosf/tanf/powf. tests/test_oracle.py::test_contract_vs_literal_build
+ *       shows the two builds agree to Monte-Carlo-branch-flip level, and
+ *       tests/test_gpu_strict.py compares the HIP path with THIS build directly.
  *
  * Compile: see oracle/Makefile (gcc -O2 -std=c11 -fopenmp -mfma -ffp-contract=off).
  */

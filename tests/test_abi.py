@@ -43,10 +43,32 @@ def test_scene_header_symbols_exported():
 
 def test_abi_version_and_struct_sizes(lib):
     from ptmi import native
-    assert lib.ptmi_abi_version() == 1
+    assert lib.ptmi_abi_version() == native.ABI_VERSION == 2
     assert ctypes.sizeof(native.Options) == 16 * 4
-    # ptmi_stats: 5 + 64 u64, 2 f64 + u64 + 2 f64, 4 u32
-    assert ctypes.sizeof(native.Stats) == (5 + 64) * 8 + 5 * 8 + 16
+    # ptmi_stats: 5 + 64 u64, 2 f64 + u64 + 2 f64, 4 u32; ABI 2 adds 3 u64 + 6 f64
+    assert ctypes.sizeof(native.Stats) == (5 + 64) * 8 + 5 * 8 + 16 + 9 * 8
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """sizeof / offsetof of every struct the binding mirrors, as a C compiler lays out include/ptmi.h."""
+    from ptmi import native
+    src = tmp_path / "sizes.c"
+    fields = {"ptmi_options": ["max_bounces", "timing", "tile_strip", "perf_mode", "ray_sort"],
+              "ptmi_stats": ["paths", "segments_by_bounce", "gpu_ms", "extend_launches", "bvh_depth", "shadow_traced",
+                             "raygen_ms", "upload_copy_ms"]}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "ptmi.h"', 'int main(void) {']
+    for st, fs in fields.items():
+        lines.append(f'printf("{st} %zu\\n", sizeof({st}));')
+        lines += [f'printf("{st}.{f} %zu\\n", offsetof({st}, {f}));' for f in fs]
+    lines += ['return 0; }']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for st, cls in (("ptmi_options", native.Options), ("ptmi_stats", native.Stats)):
+        assert int(got[st]) == ctypes.sizeof(cls), st
+        for f in fields[st]:
+            assert int(got[f"{st}.{f}"]) == getattr(cls, f).offset, f"{st}.{f}"
 
 
 def test_no_gpu_means_no_context(lib):

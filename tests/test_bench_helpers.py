@@ -1,5 +1,5 @@
 """bench.py's bookkeeping that needs no GPU: the byte model of DESIGN.md §5, the committed counter files it reads
-(profiles/r01_bench_n1_{pmc,valu}.json) and the committed bench line's contract fields."""
+(profiles/r02_cfgN_pmc.json), BASELINE.json's configurations and the committed bench lines' contract fields."""
 import importlib.util
 import json
 import os
@@ -22,22 +22,50 @@ def test_byte_model_matches_design():
     assert abs(b.pipeline_bytes_per_segment(0, 4.0) - (176 + 17)) < 1e-9
 
 
+def test_shade_byte_model():
+    b = _bench()
+    # queue 4 + hit 16 + O,D,T 48 read, 48 written, ballots 1/4, + 48 per emitted shadow record
+    assert abs(b.shade_bytes_per_segment(1, 0.5, 0.0) - (116.25 + 24)) < 1e-9
+    assert abs(b.shade_bytes_per_segment(0, 0.5, 1.0) - (116.25 - 20)) < 1e-9      # bounce 0 reads no queue, no throughput
+
+
+def test_configs_are_baseline_json():
+    """--config N = BASELINE.json configs[N]: resolution, spp, bounces, MIS, depth of field, and which scaling the N>1 run is."""
+    b = _bench()
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))["configs"]
+    assert sorted(b.CONFIGS) == list(range(len(base)))
+    c = b.CONFIGS
+    assert (c[0]["width"], c[0]["height"], c[0]["spp"], c[0]["bounces"], c[0]["mis"]) == (256, 256, 16, 4, 0)
+    assert (c[1]["scene"], c[1]["width"], c[1]["height"], c[1]["spp"], c[1]["bounces"], c[1]["mis"]) == ("cornell", 1920, 1080, 64, 8, 1)
+    assert (c[2]["scene"], c[2]["spp"]) == ("cornell_spheres", 512) and (c[3]["scene"], c[3]["spp"]) == ("grid_1m", 64)
+    assert (c[4]["width"], c[4]["height"], c[4]["spp"], c[4]["aperture"], c[4]["focus"], c[4]["scaling"]) == (3840, 2160, 256, 0.05, 2.8, "strong")
+    assert all(c[i]["scaling"] == "weak" for i in range(4))
+    for i in range(5):
+        assert c[i]["spp"] % c[i]["fps"] == 0
+
+
+def _committed(kind):
+    b = _bench()
+    return [(n, b.profile_path(n, kind)) for n in sorted(b.CONFIGS) if os.path.exists(b.profile_path(n, kind))]
+
+
 def test_committed_counter_files_feed_the_roofline():
     b = _bench()
-    traffic = b.pmc_traffic(True)
-    assert traffic is not None and 0.8e9 < traffic < 3e9                      # bytes per extend launch
-    assert b.pmc_traffic(False) is None                                       # other workloads: counters not applicable
-    v = b.valu_issue(0.8, True)
-    assert v and 3.0 < v["simd_cycles_per_instruction"] < 6.0 and v["wave_instructions_per_launch"] > 1e8
-    assert b.valu_issue(0.8, False) is None
+    have = _committed("pmc")
+    assert have, f"no profiles/{b.PROFILE_TAG}_cfgN_pmc.json committed"
+    for n, path in have:
+        traffic, src = b.pmc_traffic(n, True)
+        assert src["file"].endswith(f"{b.PROFILE_TAG}_cfg{n}_pmc.json") and src["code_commit"]
+        assert 1e7 < traffic["extend"] < 2e10 and traffic["shade"] > 0                 # bytes per launch
+        assert b.pmc_traffic(n, False) == ({}, None)                                   # other workloads: not applicable
+    assert b.pmc_traffic(0, True)[0] == {} or os.path.exists(b.profile_path(0, "pmc"))
 
 
-def test_committed_bench_line_keeps_the_contract():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_n1.json")))
+def _check_line(d):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["unit"] == "Msamples/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["unit"] == "Msamples/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
@@ -45,3 +73,20 @@ def test_committed_bench_line_keeps_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "Msamples/s" and "sample" in c
     assert d["value"] > 100 * c["value"]
+
+
+def test_committed_bench_lines_keep_the_contract():
+    _check_line(json.load(open(os.path.join(ROOT, "profiles", "r01_bench_n1.json"))))
+    b = _bench()
+    have = _committed("bench")
+    assert have, f"no profiles/{b.PROFILE_TAG}_cfgN_bench.json committed"
+    for n, path in have:
+        d = json.load(open(path))
+        _check_line(d)
+        assert d["config"]["config_index"] == n and f"configs[{n}]" in d["config"]["workload"]
+        assert d["scaling"] == b.CONFIGS[n]["scaling"]
+        # the line is self-contained: the library's per-kernel HIP-event times add up to its whole-dispatch time
+        assert abs(d["kernel_ms_sum_over_gpu_ms"] - 1.0) < 0.05
+        for k in ("extend", "shade", "shadow"):
+            e = d["roofline"]["kernels"][k]
+            assert e["launches"] > 0 and abs(e["frac"] - e["achieved"] / d["roofline"]["peak"]) < 1e-4

@@ -99,11 +99,12 @@ def _strip_worker(rank, world, port, H, W, frames, q):
         sc = scenes.make("cornell")
         cam = layout.make_camera(W, H)
         frame = np.zeros((H, W, 4), np.float32)
-        o, strip = Oracle(), sh.STRIP_ROWS
+        o, strip = Oracle(), sh.strip_rows_for(H, world)
         for y0 in range(rank * strip, H, world * strip):                          # this rank's strips only
-            o.render(sc, cam, frames, out=frame, y0=y0, y1=y0 + strip, threads=2)
+            o.render(sc, cam, frames, out=frame, y0=y0, y1=min(y0 + strip, H), threads=2)
+        assert sorted(np.flatnonzero(frame.any(axis=(1, 2)))) == sh.strip_rows(H, world, rank, strip)
         t = torch.from_numpy(frame)
-        sh.gather_strips(dist, t, world, rank)
+        sh.gather_strips(dist, t, world, rank, strip)
         dist.barrier()
         if rank == 0:
             full, _ = Oracle().render(sc, cam, frames, threads=2)
@@ -112,17 +113,67 @@ def _strip_worker(rank, world, port, H, W, frames, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_gloo_strip_gather_equals_single_render():
-    """Interleaved strips (the bench's weak-scaling shard unit): rank r renders strips r, r + 2, ...; one gather
-    de-interleaves them into the frame of a single render."""
+@pytest.mark.parametrize("H", [32, 30, 27])      # whole rounds of 4-row strips; 30 % 8 != 0 -> 3-row strips; 27: 1-row strips, odd count
+def test_two_rank_gloo_strip_gather_equals_single_render(H):
+    """Interleaved strips (the bench's shard unit): rank r renders strips r, r + 2, ...; one gather of packed rows
+    de-interleaves them into the frame of a single render. gather_strips is the code bench.py runs over RCCL: it only
+    touches contiguous send / receive buffers, so the backend sees the same tensors here and there."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_strip_worker, args=(r, 2, port, 32, 40, 2, q)) for r in range(2)]
+    procs = [ctx.Process(target=_strip_worker, args=(r, 2, port, H, 40, 2, q)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(300)
         assert p.exitcode == 0
     assert q.get(timeout=10) is True
+
+
+class _LoopbackDist:
+    """Stands in for torch.distributed in one process: gather() records what each rank sends and hands the root the
+    list a real gather would deliver. Lets the packing / unpacking run for world sizes the CPU suite does not spawn."""
+    def __init__(self, world):
+        self.world, self.sent = world, {}
+
+    def run(self, frames, strip, fn):
+        for r in range(1, self.world):                       # non-root ranks first: they only send
+            self.rank = r
+            fn(self, frames[r], self.world, r, strip)
+        self.rank = 0
+        return fn(self, frames[0], self.world, 0, strip)
+
+    def gather(self, send, recv, dst=0):
+        assert send.is_contiguous()
+        if self.rank != dst:
+            assert recv is None
+            self.sent[self.rank] = send.clone()
+            return
+        assert len(recv) == self.world and all(t.is_contiguous() and t.shape == send.shape for t in recv)
+        for r in range(self.world):
+            recv[r].copy_(send if r == dst else self.sent[r])
+
+
+@pytest.mark.parametrize("H,world", [(2160, 8), (64, 8), (37, 3), (5, 4), (1080, 1)])
+def test_strip_rows_partition_and_loopback_gather(H, world):
+    """configs[4]'s frame over 8 ranks (2160 rows -> 3-row strips), ragged frames and more ranks than strips: the rows of
+    all ranks partition the frame, and gather_strips reassembles a frame whose row y holds the value y."""
+    import torch
+    strip = shard.strip_rows_for(H, world)
+    if (H, world) == (2160, 8):
+        assert strip == 3                                    # 2160 % (4 * 8) != 0, 2160 % (3 * 8) == 0
+    rows = [shard.strip_rows(H, world, r, strip) for r in range(world)]
+    assert sorted(sum(rows, [])) == list(range(H))
+    if H % (strip * world) == 0:
+        assert len({len(r) for r in rows}) == 1              # whole rounds: equal shares
+    W = 3
+    want = torch.arange(H, dtype=torch.float32).view(H, 1, 1).expand(H, W, 4).contiguous()
+    frames = []
+    for r in range(world):
+        f = torch.full((H, W, 4), -1.0)
+        if rows[r]:
+            f[rows[r]] = want[rows[r]]
+        frames.append(f)
+    got = _LoopbackDist(world).run(frames, strip, lambda d, f, w, r, s: shard.gather_strips(d, f, w, r, s))
+    assert torch.equal(got, want)

@@ -12,7 +12,7 @@ def summarise(paths):
             a = agg[k][r['Counter_Name']]; a[0] += 1; a[1] += float(r['Counter_Value'])
             meta[k] = (r['VGPR_Count'], r['Accum_VGPR_Count'], r['SGPR_Count'], r['LDS_Block_Size'], r['Workgroup_Size'], r['Scratch_Size'])
     return agg, meta
-def to_json(paths):
+def to_json(paths, commit=None):
     """{counter: {kernel: {launches, avg_KB_per_launch}}} — the form committed as profiles/rNN_bench_n1_pmc.json.
     The two traversal kernels share a template name; they are told apart by their IO type."""
     import json
@@ -32,11 +32,16 @@ def to_json(paths):
             a[1] += float(r['Counter_Value'])
     for (c, k), (n, s) in sorted(acc.items()):
         out[c][k] = {"launches": n, ("avg_KB_per_launch" if c.endswith("_SIZE") else "avg_per_launch"): round(s / n, 2)}
+    if commit:
+        out["_code_commit"] = commit        # the commit of the code these counters measured (the GPU box has no .git)
     return json.dumps(out, indent=1)
 
 
 if __name__ == '__main__' and sys.argv[1:2] == ['--json']:
-    print(to_json(sum([glob.glob(p) for p in sys.argv[2:]], [])))
+    rest, commit = sys.argv[2:], None
+    if rest[:1] == ['--commit']:
+        commit, rest = rest[1], rest[2:]
+    print(to_json(sum([glob.glob(p) for p in rest], []), commit))
 elif __name__ == '__main__':
     agg, meta = summarise(sum([glob.glob(p) for p in sys.argv[1:]], []))
     for k in sorted(agg):

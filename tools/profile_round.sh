@@ -1,15 +1,22 @@
 #!/bin/bash
-# tools/profile_round.sh <tag>: the four runs behind profiles/<tag>_bench_n1*. Run on the GPU box from the repo root
-# (gpurun -- 'tools/profile_round.sh r01'); results land in gpurun_out/prof_<tag>/.
+# tools/profile_round.sh <tag> <config> [code-commit] [extra bench flags...]: the runs behind profiles/<tag>_cfg<config>_*.
+# Run on the GPU box from the repo root (gpurun -- 'tools/profile_round.sh r02 1 abc1234'); results land in
+# gpurun_out/prof_<tag>/ under the names they are committed with:
+#   <tag>_cfgN_bench.json         python3 bench.py --config N                                  (un-profiled line, with cpu_baseline)
+#   <tag>_cfgN_kernel_stats.csv   rocprofv3 --kernel-trace --stats -- python3 bench.py --config N
+#   <tag>_cfgN_bench_profiled.json  the line that same profiled run printed (its HIP-event launch means must agree with the CSV)
+#   <tag>_cfgN_pmc.json           separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, mean KB per launch per kernel
 set -e
-tag=${1:-r01}; root=$PWD; out=$root/gpurun_out/prof_$tag
+tag=${1:-r02}; cfg=${2:-1}; commit=${3:-unknown}; shift 3 || true
+root=$PWD; out=$root/gpurun_out/prof_$tag; pre=$out/${tag}_cfg${cfg}
 mkdir -p $out && cd /tmp && export TMPDIR=/tmp
 cd $root
-python3 bench.py > $out/bench.json 2> $out/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py > $out/bench_profiled.json 2>> $out/bench.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --no-cpu-baseline > /dev/null 2>> $out/bench.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --no-cpu-baseline > /dev/null 2>> $out/bench.err
-cp $(find $out/kt -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
-python3 tools/pmc_summary.py --json $(find $out/pmc_fetch $out/pmc_write -name "*counter_collection.csv") > $out/pmc.json
-rm -rf $out/kt $out/pmc_fetch $out/pmc_write
-cat $out/bench.json; head -12 $out/kernel_stats.csv
+python3 bench.py --config $cfg "$@" > ${pre}_bench.json 2> ${pre}.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt$cfg -- python3 bench.py --config $cfg --no-cpu-baseline "$@" > ${pre}_bench_profiled.json 2>> ${pre}.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pf$cfg -- python3 bench.py --config $cfg --no-cpu-baseline "$@" > /dev/null 2>> ${pre}.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pw$cfg -- python3 bench.py --config $cfg --no-cpu-baseline "$@" > /dev/null 2>> ${pre}.err
+cp $(find $out/kt$cfg -name "*kernel_stats.csv" | head -1) ${pre}_kernel_stats.csv
+python3 tools/per_bounce.py $(find $out/kt$cfg -name "*kernel_trace.csv" | head -1) > ${pre}_per_bounce.json || true
+python3 tools/pmc_summary.py --json --commit $commit $(find $out/pf$cfg $out/pw$cfg -name "*counter_collection.csv") > ${pre}_pmc.json
+rm -rf $out/kt$cfg $out/pf$cfg $out/pw$cfg
+cat ${pre}_bench.json; head -12 ${pre}_kernel_stats.csv

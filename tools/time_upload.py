@@ -10,4 +10,6 @@ for name in sys.argv[1:] or ["cornell", "cornell_spheres", "grid_1m"]:
     for keep in (0, 1):
         ctx.set_options(keep_reference_tree=keep)
         t = time.time(); ctx.upload_scene(sc); dt = time.time() - t
-        print(f"{name:16s} triangles {len(sc.tris):8d} host prep {t_make:6.2f} s  upload(keep_reference_tree={keep}) {dt:6.3f} s", flush=True)
+        st = ctx.stats()
+        print(f"{name:16s} triangles {len(sc.tris):8d} host prep {t_make:6.2f} s  upload(keep_reference_tree={keep}) {dt:6.3f} s"
+              f"  [library: total {st.upload_ms:8.1f} ms, rebuilt hierarchy {st.upload_tree_ms:8.1f} ms, copies {st.upload_copy_ms:7.1f} ms]", flush=True)

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(TILE_WORDS) void k_tile_sums(const uint32_t *__rest
         for (int i = 0; i < TILE_WAVES; i++) { t += wsum[i]; ts += wssum[i]; }
         tile_sums[blockIdx.x] = t;
         shadow_tile_sums[blockIdx.x] = ts;
-        if (ts) atomicAdd(&stats[1], (unsigned long long)ts);          // shadow rays (integer: order-free)
+        if (ts) { atomicAdd(&stats[1], (unsigned long long)ts); atomicAdd(&stats[2], (unsigned long long)ts); }   // shadow rays, and those traced (integers: order-free)
     }
 }
 

@@ -8,6 +8,7 @@
 #include "fast_tree.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -20,7 +21,8 @@ namespace {
 
 thread_local std::string g_create_err;
 
-struct EventPair { hipEvent_t a, b; int kind; };   // kind: 0 dispatch, 1 extend, 2 shade, 3 shadow
+struct EventPair { hipEvent_t a, b; int kind; };   // kind: 0 dispatch, 1 extend, 2 shade, 3 shadow, 4 raygen, 5 compaction, 6 accumulate
+constexpr size_t kMaxPendingEvents = 4096;        // a caller that never synchronises (a preview loop) must not grow the list without bound
 
 }  // namespace
 
@@ -51,8 +53,9 @@ struct ptmi_ctx {
     uint64_t *alive = nullptr, *shadowm = nullptr;
     uint32_t *word_off = nullptr, *counts = nullptr;
     unsigned long long *d_stats = nullptr;
-    uint32_t *d_spill = nullptr;          // node-stack overflow of the global traversal variant (allocated on first use)
+    uint32_t *d_spill = nullptr;          // node-stack overflow of the global traversal variant (128 MiB on 256 CUs, allocated by ptmi_create)
     uint8_t *d_occ = nullptr;
+    float4 *d_blit_f32 = nullptr; uint32_t *d_blit_u8 = nullptr; size_t blit_px = 0;   // canvas staging of ptmi_blit, kept between calls
 
     // statistics
     ptmi_stats st{};
@@ -95,8 +98,11 @@ void drain_events(ptmi_ctx *c) {
             switch (p.kind) {
             case 0: c->st.gpu_ms += ms; break;
             case 1: c->st.extend_ms += ms; c->st.extend_launches++; break;
-            case 2: c->st.shade_ms += ms; break;
-            case 3: c->st.shadow_ms += ms; break;
+            case 2: c->st.shade_ms += ms; c->st.shade_launches++; break;
+            case 3: c->st.shadow_ms += ms; c->st.shadow_launches++; break;
+            case 4: c->st.raygen_ms += ms; break;
+            case 5: c->st.compact_ms += ms; break;
+            case 6: c->st.accumulate_ms += ms; break;
             }
         }
         c->event_pool.push_back(p.a); c->event_pool.push_back(p.b);
@@ -104,12 +110,28 @@ void drain_events(ptmi_ctx *c) {
     c->pending.clear();
 }
 
+// without a synchronisation: resolve the pairs at the front of the list whose closing event has completed
+void drain_completed_events(ptmi_ctx *c) {
+    size_t n = 0;
+    while (n < c->pending.size() && hipEventQuery(c->pending[n].b) == hipSuccess) n++;
+    if (n == 0) return;
+    std::vector<EventPair> rest(c->pending.begin() + n, c->pending.end());
+    c->pending.resize(n);
+    drain_events(c);
+    c->pending = std::move(rest);
+}
+
 struct Timed {
     ptmi_ctx *c; hipEvent_t a = nullptr, b = nullptr; int kind; bool on;
     Timed(ptmi_ctx *c_, int kind_, bool on_) : c(c_), kind(kind_), on(on_) {
         if (on) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); }
     }
-    ~Timed() { if (on) { (void)hipEventRecord(b, c->stream); c->pending.push_back({a, b, kind}); } }
+    ~Timed() {
+        if (!on) return;
+        (void)hipEventRecord(b, c->stream);
+        c->pending.push_back({a, b, kind});
+        if (c->pending.size() > kMaxPendingEvents) drain_completed_events(c);
+    }
 };
 
 void free_batch(ptmi_ctx *c) {
@@ -147,6 +169,7 @@ struct Built {
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
     uint32_t root_ref = PT_REF_NONE, depth = 0;
     uint32_t fast_root = PT_REF_NONE, fast_depth = 0;
+    double tree_ms = 0.0;                    // time spent in pt_build_fast_tree
 };
 
 uint32_t leaf_ref(const ptmi_bvh_node &n) {
@@ -172,6 +195,7 @@ int build_image(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_
     // pass 1: preorder (left first) numbering of the internal nodes
     stack.push_back({0u, 1u});
     uint32_t n_wide = 0;
+    uint64_t next_offset = 0;               // leaves must come in ascending triangle order along the left-first DFS (below)
     while (!stack.empty()) {
         Item it = stack.back(); stack.pop_back();
         if (it.node >= nn) return fail(c, PTMI_E_INVALID, "BVH child index %u out of range (%u nodes)", it.node, nn);
@@ -180,7 +204,17 @@ int build_image(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_
         b.depth = std::max(b.depth, it.depth);
         if (it.depth > 62) return fail(c, PTMI_E_UNSUPPORTED, "BVH deeper than 62 levels (the reference's own traversal stack holds 64 entries, pt.wgsl:249)");
         const ptmi_bvh_node &n = nodes[it.node];
-        if (n.triangle_count > 0) { int rc = check_leaf(it.node); if (rc) return rc; continue; }
+        if (n.triangle_count > 0) {
+            int rc = check_leaf(it.node); if (rc) return rc;
+            // pt.wgsl:274 keeps the FIRST of equally near hits in its left-first DFS; the kernels visit leaves in another
+            // order and break ties by the lowest triangle index. The two agree iff leaf ranges ascend along that DFS —
+            // true of every tree bvh.ts builds (children split one contiguous range, left = lower part, bvh.ts:114-127).
+            if (n.triangle_offset < next_offset)
+                return fail(c, PTMI_E_UNSUPPORTED, "BVH leaf %u starts at triangle %u but an earlier leaf of the left-first DFS ends at %llu: "
+                            "leaf ranges must ascend in DFS order (as bvh.ts builds them)", it.node, n.triangle_offset, (unsigned long long)next_offset);
+            next_offset = (uint64_t)n.triangle_offset + n.triangle_count;
+            continue;
+        }
         wide_of[it.node] = n_wide++;
         stack.push_back({n.right, it.depth + 1});
         stack.push_back({n.left, it.depth + 1});
@@ -219,8 +253,11 @@ int build_image(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_
                     nested = nested && nodes[ch].aabb_min[k] >= n.aabb_min[k] && nodes[ch].aabb_max[k] <= n.aabb_max[k];
         }
     }
-    if (nested && leaves.size() >= 2 && !c->opt.keep_reference_tree)
+    if (nested && leaves.size() >= 2 && !c->opt.keep_reference_tree) {
+        const auto t0 = std::chrono::steady_clock::now();
         pt_build_fast_tree(leaves, b.fast_wnodes, b.fast_root, b.fast_depth);
+        b.tree_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
     // triangle images: v0, e1 = v1 - v0, e2 = v2 - v0 (pt.wgsl:128-129; one IEEE subtraction each)
     b.tripos.resize((size_t)nt * 3);
     for (uint32_t i = 0; i < nt; i++) {
@@ -333,7 +370,7 @@ int ptmi_destroy(ptmi_ctx *c) {
     free_batch(c);
     dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_atlas); dfree(c->d_wnodes); dfree(c->d_tripos);
     dfree(c->d_fast_wnodes);
-    dfree(c->d_out_own); dfree(c->counts); dfree(c->d_stats); dfree(c->d_spill);
+    dfree(c->d_out_own); dfree(c->counts); dfree(c->d_stats); dfree(c->d_spill); dfree(c->d_blit_f32); dfree(c->d_blit_u8);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return PTMI_OK;
@@ -351,23 +388,37 @@ int ptmi_upload_scene(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const
         if (lights[i].light_type == PTMI_LIGHT_EMISSIVE && lights[i].triangle_index >= nt)
             return fail(c, PTMI_E_INVALID, "emissive light %u references triangle %u of %u", i, lights[i].triangle_index, nt);
     }
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+    const auto t_start = clk::now();
     Built b;
     int rc = build_image(c, tris, nt, nodes, nn, b);
     if (rc) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_wnodes); dfree(c->d_tripos); dfree(c->d_fast_wnodes);
+    const double build_ms = ms_since(t_start);
+    // Allocate and fill the new buffers first; the context keeps its previous scene until all of them exist.
+    const auto t_copy = clk::now();
+    void *n_tris = nullptr, *n_mats = nullptr, *n_lights = nullptr;
+    float4 *n_wnodes = nullptr, *n_tripos = nullptr, *n_fast = nullptr;
     auto up = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
-        if (bytes == 0) { bytes = 16; hipError_t e = hipMalloc(dst, bytes); if (e != hipSuccess) return e; return hipMemset(*dst, 0, bytes); }
+        if (bytes == 0) { hipError_t e = hipMalloc(dst, 16); if (e != hipSuccess) return e; return hipMemset(*dst, 0, 16); }
         hipError_t e = hipMalloc(dst, bytes); if (e != hipSuccess) return e;
         return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     };
-    HIP_TRY(c, up(&c->d_tris, tris, (size_t)nt * sizeof(ptmi_triangle)));
-    HIP_TRY(c, up(&c->d_mats, mats, (size_t)nm * sizeof(ptmi_material)));
-    HIP_TRY(c, up(&c->d_lights, lights, (size_t)nl * sizeof(ptmi_light)));
-    HIP_TRY(c, up(reinterpret_cast<void **>(&c->d_wnodes), b.wnodes.data(), b.wnodes.size() * 16));
-    HIP_TRY(c, up(reinterpret_cast<void **>(&c->d_tripos), b.tripos.data(), b.tripos.size() * 16));
     const bool fast = !b.fast_wnodes.empty();
-    if (fast) HIP_TRY(c, up(reinterpret_cast<void **>(&c->d_fast_wnodes), b.fast_wnodes.data(), b.fast_wnodes.size() * 16));
+    hipError_t e = up(&n_tris, tris, (size_t)nt * sizeof(ptmi_triangle));
+    if (e == hipSuccess) e = up(&n_mats, mats, (size_t)nm * sizeof(ptmi_material));
+    if (e == hipSuccess) e = up(&n_lights, lights, (size_t)nl * sizeof(ptmi_light));
+    if (e == hipSuccess) e = up(reinterpret_cast<void **>(&n_wnodes), b.wnodes.data(), b.wnodes.size() * 16);
+    if (e == hipSuccess) e = up(reinterpret_cast<void **>(&n_tripos), b.tripos.data(), b.tripos.size() * 16);
+    if (e == hipSuccess && fast) e = up(reinterpret_cast<void **>(&n_fast), b.fast_wnodes.data(), b.fast_wnodes.size() * 16);
+    if (e != hipSuccess) {
+        dfree(n_tris); dfree(n_mats); dfree(n_lights); dfree(n_wnodes); dfree(n_tripos); dfree(n_fast);
+        return fail(c, PTMI_E_HIP, "scene upload failed: %s (the previous scene, if any, is still in place)", hipGetErrorString(e));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));                  // nothing in flight reads the old buffers any more
+    dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_wnodes); dfree(c->d_tripos); dfree(c->d_fast_wnodes);
+    c->d_tris = n_tris; c->d_mats = n_mats; c->d_lights = n_lights;
+    c->d_wnodes = n_wnodes; c->d_tripos = n_tripos; c->d_fast_wnodes = n_fast;
     DevScene &s = c->sc;
     s.tris = static_cast<const ptmi_triangle *>(c->d_tris); s.n_tris = nt;
     s.mats = static_cast<const ptmi_material *>(c->d_mats); s.n_mats = nm;
@@ -381,6 +432,10 @@ int ptmi_upload_scene(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const
     c->bvh_depth = std::max(b.depth, b.fast_depth);           // stacks must hold either tree (irregular rays use the uploaded one)
     c->lds_scene_bytes = (size_t)s.n_wnodes * 64 + b.tripos.size() * 16;
     c->have_scene = true;
+    c->st.upload_copy_ms = ms_since(t_copy);
+    c->st.upload_tree_ms = b.tree_ms;
+    c->st.upload_ms = ms_since(t_start);
+    (void)build_ms;
     return PTMI_OK;
 }
 
@@ -467,7 +522,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
         for (uint32_t f0 = 0; f0 < n_frames; f0 += F) {
             const uint32_t fb = std::min(F, n_frames - f0);
             const uint32_t frame0 = cam->frame_index + f0;
-            pt_launch_raygen(c->stream, blocks, *cam, band, frame0, fb, c->paths, &c->counts[0]);
+            { Timed t(c, 4, t3); pt_launch_raygen(c->stream, blocks, *cam, band, frame0, fb, c->paths, &c->counts[0]); }
             int cur = 0;
             for (uint32_t b = 0; b < maxb; b++) {
                 const uint32_t *q = b == 0 ? nullptr : c->queue[cur];      // bounce 0: slot i holds path i
@@ -476,16 +531,17 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
                                                      c->alive, c->shadowm, ShadeParams{b, maxb, c->opt.do_mis, c->d_stats}); }
                 const bool nee = c->opt.do_mis && c->sc.n_lights > 0;
                 const bool last = b + 1 == maxb;
-                pt_launch_compact(c->stream, tiles, q, &c->counts[b], c->alive, nee ? c->shadowm : nullptr,
-                                  c->word_off, c->queue[cur ^ 1], &c->counts[b + 1], c->sq, &c->counts[kShadowCount],
-                                  c->d_stats, b, last ? 0 : 1);
+                { Timed t(c, 5, t3);
+                  pt_launch_compact(c->stream, tiles, q, &c->counts[b], c->alive, nee ? c->shadowm : nullptr,
+                                    c->word_off, c->queue[cur ^ 1], &c->counts[b + 1], c->sq, &c->counts[kShadowCount],
+                                    c->d_stats, b, last ? 0 : 1); }
                 if (nee) {
                     Timed t(c, 3, t3);
                     pt_launch_shadow(c->stream, blocks, cfg_shadow, c->sc, c->paths, c->sh, c->sq, &c->counts[kShadowCount], nullptr);
                 }
                 cur ^= 1;
             }
-            pt_launch_accumulate(c->stream, blocks, band, frame0, fb, c->paths.L, c->d_out);
+            { Timed t(c, 6, t3); pt_launch_accumulate(c->stream, blocks, band, frame0, fb, c->paths.L, c->d_out); }
         }
     }
     HIP_TRY(c, hipGetLastError());
@@ -544,21 +600,32 @@ int ptmi_set_stream(ptmi_ctx *c, void *s) {
     return PTMI_OK;
 }
 
-int ptmi_blit(ptmi_ctx *c, float *dst_f32, uint8_t *dst_rgba8) {
+int ptmi_blit(ptmi_ctx *c, float *dst_f32, size_t n_floats, uint8_t *dst_rgba8, size_t n_bytes) {
     if (!c) return PTMI_E_INVALID;
     if (!c->d_out) return fail(c, PTMI_E_STATE, "no output buffer (ptmi_resize)");
     if (!dst_f32 && !dst_rgba8) return PTMI_OK;
-    HIP_TRY(c, hipSetDevice(c->device));
     const size_t n = (size_t)c->W * c->H;
-    float4 *df = nullptr; uint32_t *d8 = nullptr;
-    if (dst_f32) HIP_TRY(c, hipMalloc(&df, n * 16));
-    if (dst_rgba8) HIP_TRY(c, hipMalloc(&d8, n * 4));
-    pt_launch_blit(c->stream, c->n_cu * 8, c->W, c->H, c->d_out, df, d8);
+    if (dst_f32 && n_floats != n * 4) return fail(c, PTMI_E_INVALID, "float canvas: expected %zu floats, got %zu", n * 4, n_floats);
+    if (dst_rgba8 && n_bytes != n * 4) return fail(c, PTMI_E_INVALID, "8-bit canvas: expected %zu bytes, got %zu", n * 4, n_bytes);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->blit_px != n) {                                       // staging buffers live in the context (one pair per size)
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        dfree(c->d_blit_f32); dfree(c->d_blit_u8); c->blit_px = 0;
+    }
+    if (dst_f32 && !c->d_blit_f32) HIP_TRY(c, hipMalloc(&c->d_blit_f32, n * 16));
+    if (dst_rgba8 && !c->d_blit_u8) HIP_TRY(c, hipMalloc(&c->d_blit_u8, n * 4));
+    c->blit_px = n;
+    pt_launch_blit(c->stream, c->n_cu * 8, c->W, c->H, c->d_out, dst_f32 ? c->d_blit_f32 : nullptr, dst_rgba8 ? c->d_blit_u8 : nullptr);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     drain_events(c);
-    if (dst_f32) HIP_TRY(c, hipMemcpy(dst_f32, df, n * 16, hipMemcpyDeviceToHost));
-    if (dst_rgba8) HIP_TRY(c, hipMemcpy(dst_rgba8, d8, n * 4, hipMemcpyDeviceToHost));
-    dfree(df); dfree(d8);
+    if (dst_f32) HIP_TRY(c, hipMemcpy(dst_f32, c->d_blit_f32, n * 16, hipMemcpyDeviceToHost));
+    if (dst_rgba8) HIP_TRY(c, hipMemcpy(dst_rgba8, c->d_blit_u8, n * 4, hipMemcpyDeviceToHost));
+    return PTMI_OK;
+}
+
+int ptmi_get_size(const ptmi_ctx *c, uint32_t *w, uint32_t *h) {
+    if (!c || !w || !h) return PTMI_E_INVALID;
+    *w = c->W; *h = c->H;
     return PTMI_OK;
 }
 
@@ -569,7 +636,7 @@ int ptmi_get_stats(ptmi_ctx *c, ptmi_stats *out) {
     drain_events(c);
     unsigned long long h[kStatsWords];
     HIP_TRY(c, hipMemcpy(h, c->d_stats, sizeof h, hipMemcpyDeviceToHost));
-    c->st.segments = h[0]; c->st.shadow_rays = h[1];
+    c->st.segments = h[0]; c->st.shadow_rays = h[1]; c->st.shadow_traced = h[2];
     for (int i = 0; i < 64; i++) c->st.segments_by_bounce[i] = h[8 + i];
     c->st.bvh_depth = c->bvh_depth;
     *out = c->st;
@@ -582,9 +649,10 @@ int ptmi_reset_stats(ptmi_ctx *c) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     drain_events(c);
     HIP_TRY(c, hipMemset(c->d_stats, 0, kStatsWords * sizeof(unsigned long long)));
-    uint32_t depth = c->bvh_depth;
+    const ptmi_stats old = c->st;
     std::memset(&c->st, 0, sizeof c->st);
-    c->st.bvh_depth = depth;
+    c->st.bvh_depth = c->bvh_depth;
+    c->st.upload_ms = old.upload_ms; c->st.upload_tree_ms = old.upload_tree_ms; c->st.upload_copy_ms = old.upload_copy_ms;
     return PTMI_OK;
 }
 

@@ -29,6 +29,7 @@
 #include "pt_device.h"
 #include "pt_math.h"
 #include <atomic>
+#include <type_traits>
 
 namespace {
 
@@ -185,7 +186,18 @@ struct ShadowIO {
 // accesses coalesce) and goes on with an empty one; when the LDS part runs dry it takes the last 8 spilled entries
 // back. Deep trees then need no deeper LDS stacks — the occupancy of a depth-60 scene is that of a depth-14 one — and
 // the order in which nodes are visited, hence every result, is unchanged.
-template <int MODE, bool CULL, int STACK, bool SPILL, class Mem, class IO>
+// LEAF CULL AT POP (LC; closest hit, scenes of at most 4096 triangles): a filed leaf is tested later, often after a
+// nearer hit has been found. Its entry is (15-bit truncated entry distance, triangle count - 1, first triangle); when the
+// lane comes to test it, a leaf whose stored distance already exceeds the cull limit is dropped without its triangle
+// tests. The stored distance is max(tl, 0) rounded DOWN to 7 mantissa bits, so "stored > limit" implies "tl > limit" —
+// the very test a box gets in the node step (CULL), only against the limit of the moment the leaf is tested.
+constexpr uint32_t LC_MAX_TRIS = 4096u;
+PT_DEV uint32_t lc_pack(uint32_t ref, float tl) {
+    const uint32_t tb = __float_as_uint(max1(tl, 0.0f)) >> 16;                  // sign 0: 15 bits
+    return (tb << 17) | (((ref >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) << 12) | (ref & (LC_MAX_TRIS - 1u));
+}
+
+template <int MODE, bool CULL, int STACK, bool SPILL, bool LC, class Mem, class IO>
 PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t count, uint32_t gw,
                              uint32_t total_waves, uint32_t *stk, int stride, uint32_t *spill = nullptr,
                              uint32_t spill_lanes = 0) {
@@ -259,8 +271,14 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                     if (tri_i == tri_e) {                               // next filed leaf
                         lp += stride;
                         const uint32_t ref = *lp;
-                        tri_i = ref & PT_LEAF_OFF_MASK;
-                        tri_e = tri_i + ((ref >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) + 1u;
+                        if (LC) {
+                            tri_i = ref & (LC_MAX_TRIS - 1u);
+                            const bool keep = !(__uint_as_float((ref >> 17) << 16) > limit);
+                            tri_e = keep ? tri_i + ((ref >> 12) & (PT_LEAF_MAX_TRIS - 1u)) + 1u : tri_i;
+                        } else {
+                            tri_i = ref & PT_LEAF_OFF_MASK;
+                            tri_e = tri_i + ((ref >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) + 1u;
+                        }
                     }
                     for (uint32_t ti = tri_i; ti < tri_e; ti++) {       // pt.wgsl:272-279
                         float4 a, b, c;
@@ -285,7 +303,12 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                 }
             }
         } else {
-            // NODE_STEPS box-pair steps per vote: the vote and the bookkeeping around it cost about half a step
+            // NODE_STEPS box-pair steps per vote: the vote and the bookkeeping around it cost about half a step.
+            // Two copies of the loop: lanes that walk the uploaded tree (irregular rays, use_ref) read their nodes from
+            // global memory; a wave holds such a lane almost never, and every other time it runs the copy without that
+            // per-step choice.
+            auto node_steps = [&](auto with_ref) {
+            constexpr bool REF = decltype(with_ref)::value;
             bool cn = can_node;
 #pragma unroll
             for (int rep = 0; rep < NODE_STEPS; rep++) {
@@ -295,7 +318,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                         sp = bot;
                     }
                     float4 a, b, c, r;
-                    if (use_ref) {
+                    if (REF && use_ref) {
                         load_node((glb_f4p)sc.ref_wnodes + 4u * (size_t)cur, a, b, c, r);
                     } else {
                         m.node(cur, a, b, c, r);
@@ -306,8 +329,8 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                     if (CULL) { hl = hl & !(tl > limit); hr = hr & !(tr > limit); }
                     const uint32_t lref = __float_as_uint(r.x), rref = __float_as_uint(r.y);
                     const bool ll = (lref & PT_REF_LEAF) != 0u, rl = (rref & PT_REF_LEAF) != 0u;
-                    if (hl & ll) { *lp = lref; lp -= stride; }
-                    if (hr & rl) { *lp = rref; lp -= stride; }
+                    if (hl & ll) { *lp = LC ? lc_pack(lref, tl) : lref; lp -= stride; }
+                    if (hr & rl) { *lp = LC ? lc_pack(rref, tr) : rref; lp -= stride; }
                     const bool il = hl & !ll, ir = hr & !rl;
                     const bool left_first = tl <= tr;
                     if (il & ir) { *sp = left_first ? rref : lref; sp += stride; cur = left_first ? lref : rref; }
@@ -331,6 +354,9 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                     if (popc(ballot(cn)) * NODE_KEEP < popc(bn)) break;
                 }
             }
+            };
+            if (sc.has_fast != 0u && ballot(use_ref & active) != 0ull) node_steps(std::true_type{});
+            else node_steps(std::false_type{});
         }
         // hang guard: an active lane that can take neither stream (cannot happen while STACK > tree depth) ends here
         const bool stuck = active & !can_node & !can_tri & ((bn | bt) == 0ull);
@@ -350,7 +376,7 @@ __global__ __launch_bounds__(GBLOCK) void k_trace_global(DevScene sc, IO io, con
     const uint32_t gw = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;       // consecutive groups -> different workgroups
     if (gw * 64u >= count) return;
     GlobalMem m{(glb_f4p)sc.wnodes, (glb_f4p)sc.tripos};
-    trace_wave<MODE, CULL, STACK, true>(m, sc, io, count, gw, gridDim.x * (GBLOCK / 64), stk + threadIdx.x, GBLOCK,
+    trace_wave<MODE, CULL, STACK, true, false>(m, sc, io, count, gw, gridDim.x * (GBLOCK / 64), stk + threadIdx.x, GBLOCK,
                                         spill + (size_t)blockIdx.x * GBLOCK + threadIdx.x, gridDim.x * GBLOCK);
 }
 
@@ -365,7 +391,7 @@ __global__ __launch_bounds__(GBLOCK) void k_trace_global(DevScene sc, IO io, con
 // triangle and miss the LDS-resident triangles); ptmi_api picks per kernel.
 constexpr int LBLOCK = 1024;
 
-template <int MODE, bool CULL, int STACK, bool TRIS_IN_LDS, bool SPILL, class IO>
+template <int MODE, bool CULL, int STACK, bool TRIS_IN_LDS, bool SPILL, bool LC, class IO>
 __global__ __launch_bounds__(LBLOCK) void k_trace_lds(DevScene sc, IO io, const uint32_t *__restrict__ count_ptr,
                                                       uint32_t *__restrict__ spill) {
     extern __shared__ float4 smem[];
@@ -379,24 +405,34 @@ __global__ __launch_bounds__(LBLOCK) void k_trace_lds(DevScene sc, IO io, const 
     if (gw * 64u >= count) return;
     LdsMem<TRIS_IN_LDS> m{(lds_f4p)smem, (lds_f4p)(smem + nw), (glb_f4p)sc.tripos};
     uint32_t *stk = reinterpret_cast<uint32_t *>(smem + nw + nt) + threadIdx.x;
-    trace_wave<MODE, CULL, STACK, SPILL>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk, LBLOCK,
+    trace_wave<MODE, CULL, STACK, SPILL, LC>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk, LBLOCK,
                                          SPILL ? spill + (size_t)blockIdx.x * LBLOCK + threadIdx.x : nullptr, gridDim.x * LBLOCK);
 }
 
-template <int MODE, bool CULL, int STACK, bool TRIS, bool SPILL = false, class IO>
-void launch_lds(hipStream_t s, int wgs, size_t bytes, const DevScene &sc, const IO &io, const uint32_t *count,
-                uint32_t *spill = nullptr) {
+#ifndef PT_LEAF_CULL
+#define PT_LEAF_CULL 1
+#endif
+template <int MODE, bool CULL, int STACK, bool TRIS, bool SPILL, bool LC, class IO>
+void launch_lds_lc(hipStream_t s, int wgs, size_t bytes, const DevScene &sc, const IO &io, const uint32_t *count, uint32_t *spill) {
     // the default dynamic-LDS cap is 64 KB; raise it once per instantiation and device
     static std::atomic<uint64_t> raised{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     const uint64_t bit = 1ull << (dev & 63);
     if (!(raised.load(std::memory_order_relaxed) & bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_lds<MODE, CULL, STACK, TRIS, SPILL, IO>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_lds<MODE, CULL, STACK, TRIS, SPILL, LC, IO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         raised.fetch_or(bit, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((k_trace_lds<MODE, CULL, STACK, TRIS, SPILL, IO>), dim3(wgs), dim3(LBLOCK), bytes, s, sc, io, count, spill);
+    hipLaunchKernelGGL((k_trace_lds<MODE, CULL, STACK, TRIS, SPILL, LC, IO>), dim3(wgs), dim3(LBLOCK), bytes, s, sc, io, count, spill);
+}
+template <int MODE, bool CULL, int STACK, bool TRIS, bool SPILL = false, class IO>
+void launch_lds(hipStream_t s, int wgs, size_t bytes, const DevScene &sc, const IO &io, const uint32_t *count,
+                uint32_t *spill = nullptr) {
+    // leaf cull at pop: closest hit with the distance cull on, and triangle indices that fit the packed entry
+    constexpr bool CAN_LC = PT_LEAF_CULL != 0 && MODE == MODE_EXTEND && CULL;
+    if (CAN_LC && sc.n_tris <= LC_MAX_TRIS) launch_lds_lc<MODE, CULL, STACK, TRIS, SPILL, CAN_LC>(s, wgs, bytes, sc, io, count, spill);
+    else launch_lds_lc<MODE, CULL, STACK, TRIS, SPILL, false>(s, wgs, bytes, sc, io, count, spill);
 }
 
 // The persistent grid of the global variant is exactly the workgroups that are resident at once: every workgroup

@@ -232,7 +232,17 @@ static napi_value js_blit(napi_env env, napi_callback_info info) {
     void *p; size_t n;
     if (!get_bytes(env, argv[1], &p, &n)) return NULL;
     if (!p) { napi_throw_type_error(env, NULL, "expected a Uint8Array of width*height*4 bytes"); return NULL; }
-    int rc = ptmi_blit(ctx, NULL, (uint8_t *)p);
+    /* the library writes width*height*4 bytes: a short (or stale, after resize()) array must not reach it */
+    uint32_t w = 0, h = 0;
+    int rc = ptmi_get_size(ctx, &w, &h);
+    if (rc) return throw_ptmi(env, ctx, rc, "ptmi_get_size");
+    if (n != (size_t)w * h * 4) {
+        char msg[128];
+        snprintf(msg, sizeof msg, "blit: expected a Uint8Array of %zu bytes (%ux%ux4), got %zu", (size_t)w * h * 4, w, h, n);
+        napi_throw_range_error(env, NULL, msg);
+        return NULL;
+    }
+    rc = ptmi_blit(ctx, NULL, 0, (uint8_t *)p, n);
     if (rc) return throw_ptmi(env, ctx, rc, "ptmi_blit");
     return argv[1];
 }
@@ -256,6 +266,7 @@ static napi_value js_get_stats(napi_env env, napi_callback_info info) {
     set_num(env, o, "shadowRays", (double)s.shadow_rays); set_num(env, o, "frames", (double)s.frames);
     set_num(env, o, "dispatches", (double)s.dispatches); set_num(env, o, "gpuMs", s.gpu_ms);
     set_num(env, o, "extendMs", s.extend_ms); set_num(env, o, "shadeMs", s.shade_ms); set_num(env, o, "shadowMs", s.shadow_ms);
+    set_num(env, o, "shadowTraced", (double)s.shadow_traced); set_num(env, o, "uploadMs", s.upload_ms);
     set_num(env, o, "bvhDepth", s.bvh_depth); set_num(env, o, "traversalUsed", s.traversal_used);
     return o;
 }

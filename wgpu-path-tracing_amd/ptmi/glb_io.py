@@ -122,6 +122,38 @@ def write_glb(path, meshes, nodes, materials, lights=None, images=None, textures
         f.write(struct.pack("<II", len(binary), 0x004E4942) + binary)
 
 
+def scene_to_glb(scene, path):
+    """Writes a Scene (ptmi.scenes) as a binary glTF: one mesh primitive per material, unindexed triangles in the
+    scene's order, material factors and the emissive-strength / transmission / ior extensions the reference's loader
+    reads (src/renderer/gpu.ts:275-399). Textures are not written (the synthetic Cornell has none). The Node host loads
+    the file like any other .glb — parse, world transforms, BVH, light list — so BASELINE configs[0] ("Cornell Box glTF")
+    can be rendered literally."""
+    tris, mats = scene.tris, scene.mats
+    meshes, nodes, materials = [], [], []
+    for mi in range(len(mats)):
+        t = tris[tris["material_index"] == mi]
+        if not len(t):
+            continue
+        pos = np.stack([t["v0"], t["v1"], t["v2"]], 1).reshape(-1, 3)
+        nrm = np.stack([t["n0"], t["n1"], t["n2"]], 1).reshape(-1, 3)
+        uv = np.stack([t["uv0"], t["uv1"], t["uv2"]], 1).reshape(-1, 2)
+        if len(pos) > 65535:
+            raise ValueError("scene_to_glb writes uint16 indices: at most 21845 triangles per material")
+        m = mats[mi]
+        f = lambda v: [float(x) for x in np.atleast_1d(v)]
+        mat = {"pbrMetallicRoughness": {"baseColorFactor": f(m["base_color"]) + [1.0], "metallicFactor": float(m["metallic"]),
+                                        "roughnessFactor": float(m["roughness"])},
+               "extensions": {"KHR_materials_ior": {"ior": float(m["ior"])},
+                              "KHR_materials_transmission": {"transmissionFactor": float(m["transmission"])}}}
+        if np.any(m["emission"] > 0):
+            mat["emissiveFactor"] = f(m["emission"])
+            mat["extensions"]["KHR_materials_emissive_strength"] = {"emissiveStrength": float(m["emissive_strength"])}
+        meshes.append({"positions": pos, "normals": nrm, "uvs": uv, "indices": np.arange(len(pos)), "material": len(materials)})
+        materials.append(mat)
+        nodes.append({"mesh": len(meshes) - 1})
+    write_glb(path, meshes, nodes, materials)
+
+
 def load_blob_dir(d, name="glb"):
     """The .bin blobs written by host/prepare_cli.js -> Scene."""
     import os

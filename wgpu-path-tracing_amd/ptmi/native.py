@@ -21,8 +21,9 @@ EXPORTS = [
     "ptmi_upload_atlas", "ptmi_resize", "ptmi_set_options", "ptmi_get_options", "ptmi_dispatch",
     "ptmi_synchronize", "ptmi_read_output", "ptmi_write_output", "ptmi_output_device_ptr",
     "ptmi_bind_output_device", "ptmi_set_stream", "ptmi_blit", "ptmi_get_stats", "ptmi_reset_stats",
-    "ptmi_debug_raygen", "ptmi_debug_intersect", "ptmi_debug_occluded", "ptmi_debug_math",
+    "ptmi_debug_raygen", "ptmi_debug_intersect", "ptmi_debug_occluded", "ptmi_debug_math", "ptmi_get_size",
 ]
+ABI_VERSION = 2
 
 
 class PtmiError(RuntimeError):
@@ -37,7 +38,7 @@ class Options(ctypes.Structure):
                 ("frames_per_batch", ctypes.c_uint32), ("traversal", ctypes.c_uint32),
                 ("cull", ctypes.c_uint32), ("timing", ctypes.c_uint32), ("keep_reference_tree", ctypes.c_uint32),
                 ("tile_parts", ctypes.c_uint32), ("tile_part", ctypes.c_uint32), ("tile_strip", ctypes.c_uint32),
-                ("reserved", ctypes.c_uint32 * 4)]
+                ("perf_mode", ctypes.c_uint32), ("ray_sort", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 2)]
 
 
 class Stats(ctypes.Structure):
@@ -47,7 +48,10 @@ class Stats(ctypes.Structure):
                 ("gpu_ms", ctypes.c_double), ("extend_ms", ctypes.c_double), ("extend_launches", ctypes.c_uint64),
                 ("shade_ms", ctypes.c_double), ("shadow_ms", ctypes.c_double),
                 ("bvh_depth", ctypes.c_uint32), ("traversal_used", ctypes.c_uint32),
-                ("frames_per_batch_used", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+                ("frames_per_batch_used", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("shadow_traced", ctypes.c_uint64), ("shade_launches", ctypes.c_uint64), ("shadow_launches", ctypes.c_uint64),
+                ("raygen_ms", ctypes.c_double), ("compact_ms", ctypes.c_double), ("accumulate_ms", ctypes.c_double),
+                ("upload_ms", ctypes.c_double), ("upload_tree_ms", ctypes.c_double), ("upload_copy_ms", ctypes.c_double)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("segments_by_bounce", "reserved")}
@@ -85,7 +89,10 @@ def load():
         L.ptmi_write_output.argtypes = [vp, vp, sz]
         L.ptmi_bind_output_device.argtypes = [vp, vp, sz]
         L.ptmi_set_stream.argtypes = [vp, vp]
-        L.ptmi_blit.argtypes = [vp, vp, vp]
+        L.ptmi_blit.argtypes = [vp, vp, sz, vp, sz]
+        L.ptmi_get_size.argtypes = [vp, vp, vp]
+        if L.ptmi_abi_version() != ABI_VERSION:
+            raise PtmiError(-1, f"{LIB_PATH} has ABI {L.ptmi_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
         L.ptmi_get_stats.argtypes = [vp, vp]
         L.ptmi_reset_stats.argtypes = [vp]
         L.ptmi_debug_raygen.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp]
@@ -192,7 +199,7 @@ class Context:
         """The reference's blit pass (blit.wgsl): (canvas float RGBA or None, canvas uint8 RGBA or None), row 0 = top."""
         f = np.empty((self.height, self.width, 4), np.float32) if want_f32 else None
         b = np.empty((self.height, self.width, 4), np.uint8) if want_rgba8 else None
-        self._ck(self.L.ptmi_blit(self.h, _p(f), _p(b)))
+        self._ck(self.L.ptmi_blit(self.h, _p(f), 0 if f is None else f.size, _p(b), 0 if b is None else b.size))
         return f, b
 
     def stats(self):

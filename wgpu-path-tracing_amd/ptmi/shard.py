@@ -69,20 +69,45 @@ def strip_options(world, rank, strip=STRIP_ROWS):
                 tile_strip=strip)
 
 
+def strip_rows_for(height, world, strip=STRIP_ROWS):
+    """Strip height for `world` ranks: STRIP_ROWS when the frame is a whole number of rounds of that, else the largest
+    smaller height that is (3840x2160 over 8 ranks: 2160 % 32 != 0 -> 3-row strips). Ragged frames work with any strip
+    (the last round is short); a whole number of rounds only keeps every rank's share equal."""
+    if world <= 1:
+        return strip
+    for s in range(strip, 0, -1):
+        if height % (s * world) == 0:
+            return s
+    return strip
+
+
+def strip_rows(height, world, rank, strip=STRIP_ROWS):
+    """Frame rows of rank `rank`, ascending: strips rank, rank + world, ... of `strip` rows (the last may be short) —
+    the rows include/ptmi.h's tile_parts / tile_part / tile_strip make a context render (DevBand::row_of)."""
+    rows = []
+    for s0 in range(rank * strip, height, world * strip):
+        rows.extend(range(s0, min(s0 + strip, height)))
+    return rows
+
+
 def gather_strips(dist, frame, world, rank, strip=STRIP_ROWS, dst=0):
-    """frame: (height, width, 4) tensor whose strips rank, rank + world, ... are valid on rank `rank`
-    (height % (strip * world) == 0). ONE gather; afterwards rank `dst` holds the complete frame."""
+    """frame: (height, width, 4) tensor whose rows strip_rows(height, world, rank, strip) are valid on rank `rank`.
+    ONE gather of contiguous buffers (each rank packs its rows; the root unpacks them by row index); afterwards rank
+    `dst` holds the complete frame. The same code runs on CPU tensors with gloo and on device tensors with RCCL."""
     if world == 1:
         return frame
+    import torch
     h = frame.shape[0]
-    if h % (strip * world):
-        raise ValueError(f"{h} rows are not a whole number of rounds of {world} strips of {strip} rows")
-    rounds = frame.view(h // (strip * world), world, strip, *frame.shape[1:])   # [round, owner, row in strip, x, c]
-    mine = rounds[:, rank].contiguous()
-    recv = [mine.new_empty(mine.shape) for _ in range(world)] if rank == dst else None
-    dist.gather(mine, recv, dst=dst)
+    rows = [strip_rows(h, world, r, strip) for r in range(world)]
+    nmax = max(len(r) for r in rows)
+    idx = [torch.tensor(r, dtype=torch.long, device=frame.device) for r in rows]
+    send = frame.new_zeros((nmax,) + tuple(frame.shape[1:]))
+    if len(rows[rank]):
+        send[: len(rows[rank])] = frame.index_select(0, idx[rank])
+    recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, recv, dst=dst)
     if rank == dst:
         for r in range(world):
-            if r != dst:
-                rounds[:, r] = recv[r]
+            if r != dst and len(rows[r]):
+                frame.index_copy_(0, idx[r], recv[r][: len(rows[r])])
     return frame
