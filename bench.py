@@ -153,7 +153,7 @@ def main():
     ap.add_argument("--aperture", type=float, default=None)
     ap.add_argument("--focus-distance", type=float, default=None)
     ap.add_argument("--frames-per-batch", type=int, default=0)
-    ap.add_argument("--traversal", default="auto", choices=["auto", "global", "lds"])
+    ap.add_argument("--traversal", default="auto", choices=["auto", "global", "lds", "global_exact"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--perf-mode", type=int, default=0, help="library option perf_mode (0 = parity arithmetic, the headline)")
     ap.add_argument("--sort", type=int, default=None, help="library option ray_sort (default: the library's)")
@@ -230,7 +230,8 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
-    trav = {"auto": native.TRAVERSAL_AUTO, "global": native.TRAVERSAL_GLOBAL, "lds": native.TRAVERSAL_LDS}[args.traversal]
+    trav = {"auto": native.TRAVERSAL_AUTO, "global": native.TRAVERSAL_GLOBAL, "lds": native.TRAVERSAL_LDS,
+            "global_exact": native.TRAVERSAL_GLOBAL_EXACT}[args.traversal]
     extra = {}
     if args.perf_mode:
         extra["perf_mode"] = args.perf_mode

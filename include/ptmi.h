@@ -39,7 +39,10 @@ enum {
 };
 
 enum { PTMI_ATLAS_RGBA16F = 1, PTMI_ATLAS_RGBA32F = 2 };   /* reference uploads rgba16float (renderer.ts:246-261) */
-enum { PTMI_TRAVERSAL_AUTO = 0, PTMI_TRAVERSAL_GLOBAL = 1, PTMI_TRAVERSAL_LDS = 2 };
+/* AUTO: the scene's traversal image lives in LDS when it fits, else it is walked from global memory. GLOBAL / LDS force
+ * one (LDS fails for scenes that do not fit). GLOBAL_EXACT: global memory, on the exact 64-byte nodes instead of the
+ * quantised 32-byte image GLOBAL uses (same results; kept for tests and comparisons). */
+enum { PTMI_TRAVERSAL_AUTO = 0, PTMI_TRAVERSAL_GLOBAL = 1, PTMI_TRAVERSAL_LDS = 2, PTMI_TRAVERSAL_GLOBAL_EXACT = 3 };
 
 typedef struct ptmi_ctx ptmi_ctx;
 
@@ -166,6 +169,13 @@ int ptmi_debug_intersect(ptmi_ctx *ctx, uint32_t n, const float *o3, const float
 /* shadow kernel predicate (pt.wgsl:394/423/465); dist[i] < 0 = directional. */
 int ptmi_debug_occluded(ptmi_ctx *ctx, uint32_t n, const float *o3, const float *d3,
                         const float *dist, uint8_t *occluded);
+/* Host-only (no context, no device): builds the traversal image ptmi_upload_scene would build and reports on it.
+ * out[0] wide nodes of the rebuilt hierarchy (0: the tree is walked as uploaded), [1] leaves, [2] its depth,
+ * [3] quantised nodes (0: none), [4] dwords of the leaf stream, [5] quantised child boxes that do NOT contain the exact
+ * box they stand for (must be 0), [6] mean relative growth of box surface area by the quantisation, [7] leaf headers or
+ * triangle records of the stream that differ from the uploaded leaf box / triangles (must be 0). */
+int ptmi_debug_image_stats(const ptmi_triangle *triangles, uint32_t n_triangles,
+                           const ptmi_bvh_node *bvh_nodes, uint32_t n_nodes, double out[8]);
 /* arithmetic-contract probe: out[i] = op(a[i], b[i], c[i]) evaluated on the device.
  * ops: 0 a/b, 1 sqrt(a), 2 fma(a,b,c), 3 min(a,b), 4 max(a,b), 5 sin(a), 6 cos(a),
  *      7 pow5(a), 8 f32(u32 bits of a), 9 u32(a) as bits, 10 a - trunc(a), 11 tan(a) */

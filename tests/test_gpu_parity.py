@@ -86,12 +86,12 @@ def _test_rays(scene, n, seed):
 
 @pytest.mark.parametrize("name", ["cornell", "feature_box", "cornell_spheres", "grid_1m"])
 @pytest.mark.parametrize("cull", [1, 0])
-@pytest.mark.parametrize("trav", ["global", "lds"])
+@pytest.mark.parametrize("trav", ["global", "global_exact", "lds"])      # global = the quantised 32-byte image
 def test_extend_parity(gpu_ctx, oracle, scene_factory, name, cull, trav):
     from ptmi import native
     sc = scene_factory(name)
     gpu_ctx.upload_scene(sc)
-    mode = native.TRAVERSAL_GLOBAL if trav == "global" else native.TRAVERSAL_AUTO
+    mode = {"global": native.TRAVERSAL_GLOBAL, "global_exact": native.TRAVERSAL_GLOBAL_EXACT, "lds": native.TRAVERSAL_AUTO}[trav]
     gpu_ctx.set_options(cull=cull, traversal=mode)
     o, d = _test_rays(sc, 300_000, 11)
     gt, gtri, gu, gv = gpu_ctx.debug_intersect(o, d)
@@ -106,12 +106,13 @@ def test_extend_parity(gpu_ctx, oracle, scene_factory, name, cull, trav):
 
 @pytest.mark.parametrize("name", ["cornell", "feature_box", "cornell_spheres"])
 @pytest.mark.parametrize("keep", [0, 1])
-def test_irregular_rays_parity(gpu_ctx, oracle, scene_factory, name, keep):
+@pytest.mark.parametrize("trav", [0, 1])       # auto (LDS for these scenes) and global: there the irregular lanes read the
+def test_irregular_rays_parity(gpu_ctx, oracle, scene_factory, name, keep, trav):      # uploaded tree beside lanes on the quantised one
     """Rays with zero / subnormal direction components, started exactly on box planes and triangle vertices:
     the cases where the slab test produces inf and NaN (pt.wgsl:235-236). The rebuilt hierarchy must not be
     used for them (csrc/fast_tree.hip); with keep_reference_tree=1 nothing is rebuilt at all."""
     sc = scene_factory(name)
-    gpu_ctx.set_options(keep_reference_tree=keep, cull=1, traversal=0)
+    gpu_ctx.set_options(keep_reference_tree=keep, cull=1, traversal=trav)
     gpu_ctx.upload_scene(sc)
     rng = np.random.default_rng(21)
     n = 60_000
@@ -139,7 +140,7 @@ def test_irregular_rays_parity(gpu_ctx, oracle, scene_factory, name, keep):
     dist = (rng.random(n) * 2.0).astype(np.float32)
     dist[::3] = -1
     assert np.array_equal(gpu_ctx.debug_occluded(o, d, dist), oracle.occluded(sc, o, d, dist))
-    gpu_ctx.set_options(keep_reference_tree=0)
+    gpu_ctx.set_options(keep_reference_tree=0, traversal=0)
     gpu_ctx.upload_scene(sc)
 
 
@@ -246,7 +247,7 @@ def test_tile_rows_and_traversal_modes(gpu_ctx, oracle, scene_factory):
     ref, _ = oracle.render(sc, cam, frames)
     gpu_ctx.upload_scene(sc)
     for mode, cull in ((native.TRAVERSAL_GLOBAL, 1), (native.TRAVERSAL_LDS, 1), (native.TRAVERSAL_GLOBAL, 0),
-                       (native.TRAVERSAL_LDS, 0)):
+                       (native.TRAVERSAL_LDS, 0), (native.TRAVERSAL_GLOBAL_EXACT, 1), (native.TRAVERSAL_GLOBAL_EXACT, 0)):
         gpu_ctx.resize(W, H)
         gpu_ctx.set_options(max_bounces=8, do_mis=1, traversal=mode, cull=cull, frames_per_batch=0, tile_y0=0, tile_y1=0)
         for y0, y1 in ((0, 17), (17, 40), (40, 60)):
@@ -293,7 +294,8 @@ def test_random_scene_fuzz(gpu_ctx, oracle, seed):
     d[::17, rng.integers(0, 3)] = 0.0                                  # some irregular rays
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     t_ref, tri_ref, u_ref, v_ref, _ = oracle.intersect(sc, o, d)
-    for keep, trav in ((0, native.TRAVERSAL_AUTO), (1, native.TRAVERSAL_GLOBAL), (0, native.TRAVERSAL_GLOBAL)):
+    for keep, trav in ((0, native.TRAVERSAL_AUTO), (1, native.TRAVERSAL_GLOBAL), (0, native.TRAVERSAL_GLOBAL),
+                       (0, native.TRAVERSAL_GLOBAL_EXACT)):
         gpu_ctx.set_options(keep_reference_tree=keep)
         gpu_ctx.upload_scene(sc)
         gpu_ctx.resize(W, H)

@@ -14,3 +14,13 @@ struct PtFastLeaf {
 // leaf reference when there is a single leaf; depth: levels including the leaves.
 void pt_build_fast_tree(const std::vector<PtFastLeaf> &leaves, std::vector<float4> &wnodes, uint32_t &root_ref,
                         uint32_t &depth);
+
+// Quantised image of that hierarchy for the global traversal variant (layout: traverse.hip, QuantMem).
+//   qnodes      2 uint4 per wide node: child boxes as 16-bit plane numbers on the grid origin + k * scale, rounded outward
+//               (verified with the same fmaf the kernel evaluates), child references (leaf: PT_REF_LEAF | dword offset into
+//               `stream`)
+//   stream      per leaf: exact box (the reference node's), first triangle, count, then v0, e1, e2 of each triangle (9 dwords)
+// tripos: 3 float4 per triangle (v0, e1, e2), indexed by triangle. Returns false when the hierarchy cannot be quantised
+// (non-finite boxes, a stream beyond 2^31 dwords); the caller then keeps the exact image.
+bool pt_quantize_tree(const std::vector<PtFastLeaf> &leaves, const std::vector<float4> &wnodes, const std::vector<float4> &tripos,
+                      std::vector<uint4> &qnodes, std::vector<uint32_t> &stream, float origin[3], float scale[3]);

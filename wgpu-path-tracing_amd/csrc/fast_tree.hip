@@ -15,11 +15,14 @@
 // tests (25.7 -> 13.6 per ray, measured). Irregular rays (a zero, subnormal or non-finite direction
 // component) keep walking the reference's own tree (traverse.hip).
 #include "fast_tree.h"
+#include "pt_device.h"
+#include <limits>
 
 #include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <unordered_map>
 
 namespace {
 
@@ -158,4 +161,92 @@ void pt_build_fast_tree(const std::vector<PtFastLeaf> &leaves, std::vector<float
     Box root;
     root_ref = b.build(0, n, 1, root);
     depth = b.depth;
+}
+
+// ---- quantised image ------------------------------------------------------------------------------------------------
+bool pt_quantize_tree(const std::vector<PtFastLeaf> &leaves, const std::vector<float4> &wnodes, const std::vector<float4> &tripos,
+                      std::vector<uint4> &qnodes, std::vector<uint32_t> &stream, float origin[3], float scale[3]) {
+    qnodes.clear(); stream.clear();
+    const size_t n_nodes = wnodes.size() / 4;
+    if (n_nodes == 0 || leaves.empty()) return false;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    size_t n_tri_refs = 0;
+    for (const PtFastLeaf &l : leaves) {
+        for (int k = 0; k < 3; k++) {
+            if (!std::isfinite(l.mn[k]) || !std::isfinite(l.mx[k]) || l.mn[k] > l.mx[k]) return false;
+            mn[k] = std::min(mn[k], l.mn[k]); mx[k] = std::max(mx[k], l.mx[k]);
+        }
+        n_tri_refs += l.weight;
+    }
+    if (leaves.size() * 8 + n_tri_refs * 9 >= (1ull << 31)) return false;
+    for (int k = 0; k < 3; k++) {
+        origin[k] = mn[k];
+        const double ext = (double)mx[k] - (double)mn[k];
+        float s = (float)(ext / 65535.0);
+        if (!std::isfinite(s)) return false;
+        if (ext > 0.0) {
+            if (!(s > 0.0f)) s = std::numeric_limits<float>::denorm_min();
+            int guard = 0;
+            while (std::fmaf(s, 65535.0f, origin[k]) < mx[k] && guard++ < 64) s = std::nextafterf(s, INFINITY);   // the last plane reaches the far side
+            if (std::fmaf(s, 65535.0f, origin[k]) < mx[k]) return false;
+        }
+        scale[k] = s;
+    }
+    auto plane_lo = [&](int k, float v) -> uint32_t {         // largest plane number whose plane is <= v
+        if (!(scale[k] > 0.0f)) return 0u;
+        double q = std::floor(((double)v - (double)origin[k]) / (double)scale[k]);
+        uint32_t u = q <= 0.0 ? 0u : q >= 65535.0 ? 65535u : (uint32_t)q;
+        while (u > 0u && std::fmaf(scale[k], (float)u, origin[k]) > v) u--;
+        return u;
+    };
+    auto plane_hi = [&](int k, float v) -> uint32_t {         // smallest plane number whose plane is >= v
+        if (!(scale[k] > 0.0f)) return 0u;
+        double q = std::ceil(((double)v - (double)origin[k]) / (double)scale[k]);
+        uint32_t u = q <= 0.0 ? 0u : q >= 65535.0 ? 65535u : (uint32_t)q;
+        while (u < 65535u && std::fmaf(scale[k], (float)u, origin[k]) < v) u++;
+        return u;
+    };
+    // the leaf stream, in the order the leaves hang off the preorder nodes (neighbours in the tree are neighbours in memory)
+    std::unordered_map<uint32_t, const PtFastLeaf *> by_ref;
+    by_ref.reserve(leaves.size() * 2);
+    for (const PtFastLeaf &l : leaves) by_ref[l.ref] = &l;
+    stream.reserve(leaves.size() * 8 + n_tri_refs * 9);
+    auto emit_leaf = [&](uint32_t ref) -> uint32_t {
+        const PtFastLeaf &l = *by_ref.at(ref);
+        const uint32_t off = (uint32_t)stream.size();
+        const uint32_t first = ref & PT_LEAF_OFF_MASK, cnt = ((ref >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) + 1u;
+        auto put = [&](float f) { uint32_t u; std::memcpy(&u, &f, 4); stream.push_back(u); };
+        put(l.mn[0]); put(l.mn[1]); put(l.mn[2]); stream.push_back(first);
+        put(l.mx[0]); put(l.mx[1]); put(l.mx[2]); stream.push_back(cnt);
+        for (uint32_t t = first; t < first + cnt; t++)
+            for (int j = 0; j < 3; j++) { const float4 &v = tripos[3 * (size_t)t + j]; put(v.x); put(v.y); put(v.z); }
+        return PT_REF_LEAF | off;
+    };
+    qnodes.resize(n_nodes * 2);
+    double growth = 0.0; size_t grown = 0;       // mean relative growth of the child boxes' surface area
+    auto area = [](const float *l, const float *h) {
+        const double x = (double)h[0] - l[0], y = (double)h[1] - l[1], z = (double)h[2] - l[2];
+        return 2.0 * (x * y + y * z + z * x);
+    };
+    for (size_t i = 0; i < n_nodes; i++) {
+        const float4 *w = &wnodes[i * 4];
+        const float lo[2][3] = {{w[0].x, w[0].y, w[0].z}, {w[1].z, w[1].w, w[2].x}};
+        const float hi[2][3] = {{w[0].w, w[1].x, w[1].y}, {w[2].y, w[2].z, w[2].w}};
+        uint32_t refs[2]; std::memcpy(&refs[0], &w[3].x, 4); std::memcpy(&refs[1], &w[3].y, 4);
+        for (int c = 0; c < 2; c++) {
+            uint32_t ql[3], qh[3];
+            for (int k = 0; k < 3; k++) { ql[k] = plane_lo(k, lo[c][k]); qh[k] = plane_hi(k, hi[c][k]); }
+            const uint32_t ref = (refs[c] & PT_REF_LEAF) ? emit_leaf(refs[c]) : refs[c];
+            qnodes[i * 2 + c] = make_uint4(ql[0] | (ql[1] << 16), ql[2] | (qh[0] << 16), qh[1] | (qh[2] << 16), ref);
+            float dl[3], dh[3];
+            for (int k = 0; k < 3; k++) { dl[k] = std::fmaf(scale[k], (float)ql[k], origin[k]); dh[k] = std::fmaf(scale[k], (float)qh[k], origin[k]); }
+            const double a0 = area(lo[c], hi[c]);
+            if (a0 > 0.0) { growth += std::min(area(dl, dh) / a0 - 1.0, 1e6); grown++; }
+        }
+    }
+    // One grid for the whole scene suits scenes whose boxes are not many orders of magnitude smaller than the scene.
+    // Where they are (a chain of boxes shrinking geometrically), the rounded boxes would admit far more rays than the exact
+    // ones: same results, much more work. Such scenes keep the exact image.
+    if (grown && growth / (double)grown > 0.25) { qnodes.clear(); stream.clear(); return false; }
+    return true;
 }

@@ -36,6 +36,11 @@ struct DevScene {
     // SAH tree rebuilt over the reference's leaves (fast_tree.hip, has_fast = 1) and the reference-shaped
     // image is kept for irregular rays; otherwise wnodes IS the reference-shaped image.
     const float4 *ref_wnodes;   uint32_t ref_root_ref, has_fast;
+    // Quantised image of the rebuilt hierarchy for the global traversal variant (traverse.hip QuantMem; NULL: none):
+    // 32-B nodes whose child boxes are 16-bit plane numbers on the grid origin + k * scale per axis, and the leaf stream
+    // (per leaf: exact box + first triangle + count, then 9 dwords per triangle).
+    const uint4 *qnodes;        const uint32_t *leaf_stream;
+    float q_origin[3], q_scale[3];
 };
 
 // ---- path state: 64 B per path, four float4 streams indexed by path id ----
@@ -73,6 +78,7 @@ struct TraverseConfig {
     size_t lds_scene_bytes; // LDS variant: bytes of wnodes + tripos
     int wgs_per_cu;         // node cache: 2 (small trees, whole stack in LDS) or 1 (mid-size trees, spilling stacks)
     uint32_t *spill;        // global variant: per-lane overflow of the node stack, pt_spill_bytes(blocks) bytes
+    int quantized;          // global variant: walk the quantised image when the scene has one
 };
 #define PT_SPILL_ENTRIES 64     /* >= the deepest node stack: upload rejects trees deeper than 62 */
 size_t pt_spill_bytes(int blocks);

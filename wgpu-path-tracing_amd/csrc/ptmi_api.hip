@@ -35,6 +35,7 @@ struct ptmi_ctx {
     // scene (bindings 1, 2, 4, 5, 6)
     void *d_tris = nullptr, *d_mats = nullptr, *d_lights = nullptr, *d_atlas = nullptr;
     float4 *d_wnodes = nullptr, *d_tripos = nullptr, *d_fast_wnodes = nullptr;
+    uint4 *d_qnodes = nullptr; uint32_t *d_leaf_stream = nullptr;        // quantised image of the rebuilt hierarchy (global variant)
     DevScene sc{};
     uint32_t bvh_depth = 0;
     bool have_scene = false;
@@ -82,7 +83,7 @@ template <class T> void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; }
 
 void default_options(ptmi_options &o) {
     std::memset(&o, 0, sizeof o);
-    o.max_bounces = 8; o.do_mis = 1; o.cull = 1; o.traversal = PTMI_TRAVERSAL_AUTO;
+    o.max_bounces = 8; o.do_mis = 1; o.cull = 1; o.traversal = PTMI_TRAVERSAL_AUTO; o.ray_sort = 2;
 }
 
 hipEvent_t get_event(ptmi_ctx *c) {
@@ -170,6 +171,8 @@ struct Built {
     uint32_t root_ref = PT_REF_NONE, depth = 0;
     uint32_t fast_root = PT_REF_NONE, fast_depth = 0;
     double tree_ms = 0.0;                    // time spent in pt_build_fast_tree
+    std::vector<uint4> qnodes; std::vector<uint32_t> leaf_stream;     // quantised image (empty: none)
+    float q_origin[3] = {0, 0, 0}, q_scale[3] = {0, 0, 0};
 };
 
 uint32_t leaf_ref(const ptmi_bvh_node &n) {
@@ -266,6 +269,9 @@ int build_image(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_
         b.tripos[3 * (size_t)i + 1] = make_float4(t.v1[0] - t.v0[0], t.v1[1] - t.v0[1], t.v1[2] - t.v0[2], 0.0f);
         b.tripos[3 * (size_t)i + 2] = make_float4(t.v2[0] - t.v0[0], t.v2[1] - t.v0[1], t.v2[2] - t.v0[2], 0.0f);
     }
+    if (!b.fast_wnodes.empty() && !pt_quantize_tree(leaves, b.fast_wnodes, b.tripos, b.qnodes, b.leaf_stream, b.q_origin, b.q_scale)) {
+        b.qnodes.clear(); b.leaf_stream.clear();
+    }
     return PTMI_OK;
 }
 
@@ -285,7 +291,8 @@ TraverseConfig traverse_config(const ptmi_ctx *c, bool closest_hit) {
     const bool node_cache = have && c->bvh_depth + 2 <= 16 &&
                             (size_t)c->sc.n_wnodes * 64 + (size_t)small_stack * 1024 * 4 <= kLdsMax / 2;
     cfg.spill = nullptr; cfg.wgs_per_cu = 2;
-    if (c->opt.traversal == PTMI_TRAVERSAL_GLOBAL) cfg.variant = PT_VARIANT_GLOBAL;
+    cfg.quantized = c->opt.traversal != PTMI_TRAVERSAL_GLOBAL_EXACT;
+    if (c->opt.traversal == PTMI_TRAVERSAL_GLOBAL || c->opt.traversal == PTMI_TRAVERSAL_GLOBAL_EXACT) cfg.variant = PT_VARIANT_GLOBAL;
     else if (closest_hit && node_cache && c->opt.traversal == PTMI_TRAVERSAL_AUTO) {   // any-hit: measured 15 % slower with it
         cfg.variant = PT_VARIANT_LDS_NODES; cfg.stack_entries = small_stack;
     } else if (fits) { cfg.variant = PT_VARIANT_LDS; cfg.stack_entries = lds_stack; }
@@ -369,7 +376,7 @@ int ptmi_destroy(ptmi_ctx *c) {
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     free_batch(c);
     dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_atlas); dfree(c->d_wnodes); dfree(c->d_tripos);
-    dfree(c->d_fast_wnodes);
+    dfree(c->d_fast_wnodes); dfree(c->d_qnodes); dfree(c->d_leaf_stream);
     dfree(c->d_out_own); dfree(c->counts); dfree(c->d_stats); dfree(c->d_spill); dfree(c->d_blit_f32); dfree(c->d_blit_u8);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -399,6 +406,8 @@ int ptmi_upload_scene(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const
     const auto t_copy = clk::now();
     void *n_tris = nullptr, *n_mats = nullptr, *n_lights = nullptr;
     float4 *n_wnodes = nullptr, *n_tripos = nullptr, *n_fast = nullptr;
+    uint4 *n_qnodes = nullptr; uint32_t *n_stream = nullptr;
+    const bool quant = !b.qnodes.empty();
     auto up = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
         if (bytes == 0) { hipError_t e = hipMalloc(dst, 16); if (e != hipSuccess) return e; return hipMemset(*dst, 0, 16); }
         hipError_t e = hipMalloc(dst, bytes); if (e != hipSuccess) return e;
@@ -411,12 +420,16 @@ int ptmi_upload_scene(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const
     if (e == hipSuccess) e = up(reinterpret_cast<void **>(&n_wnodes), b.wnodes.data(), b.wnodes.size() * 16);
     if (e == hipSuccess) e = up(reinterpret_cast<void **>(&n_tripos), b.tripos.data(), b.tripos.size() * 16);
     if (e == hipSuccess && fast) e = up(reinterpret_cast<void **>(&n_fast), b.fast_wnodes.data(), b.fast_wnodes.size() * 16);
+    if (e == hipSuccess && quant) e = up(reinterpret_cast<void **>(&n_qnodes), b.qnodes.data(), b.qnodes.size() * 16);
+    if (e == hipSuccess && quant) e = up(reinterpret_cast<void **>(&n_stream), b.leaf_stream.data(), b.leaf_stream.size() * 4);
     if (e != hipSuccess) {
-        dfree(n_tris); dfree(n_mats); dfree(n_lights); dfree(n_wnodes); dfree(n_tripos); dfree(n_fast);
+        dfree(n_tris); dfree(n_mats); dfree(n_lights); dfree(n_wnodes); dfree(n_tripos); dfree(n_fast); dfree(n_qnodes); dfree(n_stream);
         return fail(c, PTMI_E_HIP, "scene upload failed: %s (the previous scene, if any, is still in place)", hipGetErrorString(e));
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));                  // nothing in flight reads the old buffers any more
     dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_wnodes); dfree(c->d_tripos); dfree(c->d_fast_wnodes);
+    dfree(c->d_qnodes); dfree(c->d_leaf_stream);
+    c->d_qnodes = n_qnodes; c->d_leaf_stream = n_stream;
     c->d_tris = n_tris; c->d_mats = n_mats; c->d_lights = n_lights;
     c->d_wnodes = n_wnodes; c->d_tripos = n_tripos; c->d_fast_wnodes = n_fast;
     DevScene &s = c->sc;
@@ -427,6 +440,8 @@ int ptmi_upload_scene(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const
     s.wnodes = fast ? c->d_fast_wnodes : c->d_wnodes;
     s.n_wnodes = (uint32_t)((fast ? b.fast_wnodes.size() : b.wnodes.size()) / 4);
     s.tripos = c->d_tripos;
+    s.qnodes = c->d_qnodes; s.leaf_stream = c->d_leaf_stream;
+    for (int k = 0; k < 3; k++) { s.q_origin[k] = b.q_origin[k]; s.q_scale[k] = b.q_scale[k]; }
     for (int k = 0; k < 3; k++) { s.root_min[k] = b.root_min[k]; s.root_max[k] = b.root_max[k]; }
     s.root_ref = fast ? b.fast_root : b.root_ref;
     c->bvh_depth = std::max(b.depth, b.fast_depth);           // stacks must hold either tree (irregular rays use the uploaded one)
@@ -470,10 +485,12 @@ int ptmi_resize(ptmi_ctx *c, uint32_t w, uint32_t h) {
 int ptmi_set_options(ptmi_ctx *c, const ptmi_options *o) {
     if (!c || !o) return PTMI_E_INVALID;
     if (o->max_bounces < 1 || o->max_bounces > 64) return fail(c, PTMI_E_INVALID, "max_bounces %u not in 1..64", o->max_bounces);
-    if (o->traversal > PTMI_TRAVERSAL_LDS) return fail(c, PTMI_E_INVALID, "unknown traversal mode %u", o->traversal);
+    if (o->traversal > PTMI_TRAVERSAL_GLOBAL_EXACT) return fail(c, PTMI_E_INVALID, "unknown traversal mode %u", o->traversal);
     if (o->tile_y1 != 0 && o->tile_y0 >= o->tile_y1) return fail(c, PTMI_E_INVALID, "empty tile rows [%u,%u)", o->tile_y0, o->tile_y1);
     if (o->tile_parts > 1 && o->tile_part >= o->tile_parts)
         return fail(c, PTMI_E_INVALID, "tile_part %u is not below tile_parts %u", o->tile_part, o->tile_parts);
+    if (o->perf_mode > 1) return fail(c, PTMI_E_INVALID, "unknown perf_mode %u", o->perf_mode);
+    if (o->ray_sort > 2) return fail(c, PTMI_E_INVALID, "unknown ray_sort %u", o->ray_sort);
     c->opt = *o;
     return PTMI_OK;
 }
@@ -723,6 +740,61 @@ int ptmi_debug_occluded(ptmi_ctx *c, uint32_t n, const float *o3, const float *d
     HIP_TRY(c, hipMemcpyAsync(occ, c->d_occ, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
+    return PTMI_OK;
+}
+
+int ptmi_debug_image_stats(const ptmi_triangle *tris, uint32_t nt, const ptmi_bvh_node *nodes, uint32_t nn, double out[8]) {
+    if (!out || (nt && !tris) || (nn && !nodes)) return PTMI_E_INVALID;
+    for (int i = 0; i < 8; i++) out[i] = 0.0;
+    ptmi_ctx tmp;                                   // host-only: never touches a device
+    default_options(tmp.opt);
+    Built b;
+    int rc = build_image(&tmp, tris, nt, nodes, nn, b);
+    if (rc) { g_create_err = tmp.err; return rc; }
+    out[0] = (double)(b.fast_wnodes.size() / 4); out[2] = (double)b.fast_depth;
+    out[3] = (double)(b.qnodes.size() / 2); out[4] = (double)b.leaf_stream.size();
+    if (b.qnodes.empty()) return PTMI_OK;
+    // every quantised child box, decoded with the kernel's own fmaf, must contain the exact child box it stands for
+    double viol = 0.0, infl = 0.0; size_t boxes = 0, leaves = 0, bad_hdr = 0;
+    auto area = [](const float *lo, const float *hi) {
+        double x = (double)hi[0] - lo[0], y = (double)hi[1] - lo[1], z = (double)hi[2] - lo[2];
+        return 2.0 * (x * y + y * z + z * x);
+    };
+    for (size_t i = 0; i < b.qnodes.size() / 2; i++) {
+        const float4 *w = &b.fast_wnodes[i * 4];
+        const float lo[2][3] = {{w[0].x, w[0].y, w[0].z}, {w[1].z, w[1].w, w[2].x}};
+        const float hi[2][3] = {{w[0].w, w[1].x, w[1].y}, {w[2].y, w[2].z, w[2].w}};
+        uint32_t refs[2]; std::memcpy(&refs[0], &w[3].x, 4); std::memcpy(&refs[1], &w[3].y, 4);
+        for (int ch = 0; ch < 2; ch++) {
+            const uint4 q = b.qnodes[i * 2 + ch];
+            const uint32_t pl[6] = {q.x & 0xFFFFu, q.x >> 16, q.y & 0xFFFFu, q.y >> 16, q.z & 0xFFFFu, q.z >> 16};   // lo.xyz, hi.xyz
+            float dlo[3], dhi[3];
+            for (int k = 0; k < 3; k++) {
+                dlo[k] = std::fmaf(b.q_scale[k], (float)pl[k], b.q_origin[k]);
+                dhi[k] = std::fmaf(b.q_scale[k], (float)pl[3 + k], b.q_origin[k]);
+                if (!(dlo[k] <= lo[ch][k]) || !(dhi[k] >= hi[ch][k])) viol += 1.0;
+            }
+            const double a0 = area(lo[ch], hi[ch]);
+            if (a0 > 0.0) { infl += area(dlo, dhi) / a0 - 1.0; boxes++; }
+            if (refs[ch] & PT_REF_LEAF) {
+                leaves++;
+                if (!(q.w & PT_REF_LEAF)) { bad_hdr++; continue; }
+                const uint32_t *h = &b.leaf_stream[q.w & ~PT_REF_LEAF];
+                float hl[3], hh[3]; std::memcpy(hl, h, 12); std::memcpy(hh, h + 4, 12);
+                const uint32_t first = refs[ch] & PT_LEAF_OFF_MASK, cnt = ((refs[ch] >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) + 1u;
+                bool ok = h[3] == first && h[7] == cnt;
+                for (int k = 0; k < 3; k++) ok = ok && hl[k] == lo[ch][k] && hh[k] == hi[ch][k];
+                for (uint32_t t = 0; t < cnt && ok; t++)
+                    for (int j = 0; j < 3; j++) {
+                        const float4 &v = b.tripos[3 * (size_t)(first + t) + j];
+                        float g[3]; std::memcpy(g, h + 8 + 9 * t + 3 * j, 12);
+                        ok = ok && std::memcmp(&g[0], &v.x, 4) == 0 && std::memcmp(&g[1], &v.y, 4) == 0 && std::memcmp(&g[2], &v.z, 4) == 0;
+                    }
+                if (!ok) bad_hdr++;
+            } else if (q.w != refs[ch]) bad_hdr++;
+        }
+    }
+    out[1] = (double)leaves; out[5] = viol; out[6] = boxes ? infl / (double)boxes : 0.0; out[7] = (double)bad_hdr;
     return PTMI_OK;
 }
 

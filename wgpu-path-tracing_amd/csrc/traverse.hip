@@ -73,11 +73,30 @@ PT_DEV void load_node(glb_f4p p, float4 &a, float4 &b, float4 &c, float4 &d) {
     a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]); d = as_f4(p[3]);
 }
 
+// ---- node / leaf access policies ---------------------------------------------------------------------------------
+// node(i, old, b)   : both child boxes and child references of wide node i
+// open(ref, ...)    : a filed leaf -> its triangle range (first index, count) and a cursor for tri(); false = skip it
+// tri(cursor, k, ..): v0, e1, e2 of the leaf's k-th triangle
+// `old` marks a lane that walks the tree exactly as uploaded (irregular rays): only the quantised
+// variant stores that tree in a different format than the one it normally walks.
+struct Boxes { float lx0, ly0, lz0, lx1, ly1, lz1, rx0, ry0, rz0, rx1, ry1, rz1; uint32_t lref, rref; };
+PT_DEV void boxes_of(float4 a, float4 b, float4 c, float4 r, Boxes &o) {
+    o.lx0 = a.x; o.ly0 = a.y; o.lz0 = a.z; o.lx1 = a.w; o.ly1 = b.x; o.lz1 = b.y;
+    o.rx0 = b.z; o.ry0 = b.w; o.rz0 = c.x; o.rx1 = c.y; o.ry1 = c.z; o.rz1 = c.w;
+    o.lref = __float_as_uint(r.x); o.rref = __float_as_uint(r.y);
+}
+PT_DEV void open_plain(uint32_t ref, uint32_t &first, uint32_t &cnt, uint32_t &cursor) {
+    first = ref & PT_LEAF_OFF_MASK; cnt = ((ref >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) + 1u; cursor = first;
+}
+
 struct GlobalMem {
     glb_f4p wn, tp;
-    PT_DEV void node(uint32_t i, float4 &a, float4 &b, float4 &c, float4 &d) const { load_node(wn + 4u * (size_t)i, a, b, c, d); }
-    PT_DEV void tri(uint32_t i, float4 &a, float4 &b, float4 &c) const {
-        glb_f4p p = tp + 3u * (size_t)i;
+    PT_DEV void node(uint32_t i, bool, Boxes &o) const { float4 a, b, c, r; load_node(wn + 4u * (size_t)i, a, b, c, r); boxes_of(a, b, c, r, o); }
+    PT_DEV bool open(uint32_t ref, bool, v3, v3, float, uint32_t &first, uint32_t &cnt, uint32_t &cursor) const {
+        open_plain(ref, first, cnt, cursor); return true;
+    }
+    PT_DEV void tri(uint32_t cursor, uint32_t k, bool, float4 &a, float4 &b, float4 &c) const {
+        glb_f4p p = tp + 3u * (size_t)(cursor + k);
         a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]);
     }
 };
@@ -86,13 +105,72 @@ struct GlobalMem {
 template <bool TRIS_IN_LDS>
 struct LdsMem {
     lds_f4p wn, tl; glb_f4p tg;
-    PT_DEV void node(uint32_t i, float4 &a, float4 &b, float4 &c, float4 &d) const {
+    PT_DEV void node(uint32_t i, bool, Boxes &o) const {
         lds_f4p p = wn + 4u * i;
-        a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]); d = as_f4(p[3]);
+        boxes_of(as_f4(p[0]), as_f4(p[1]), as_f4(p[2]), as_f4(p[3]), o);
     }
-    PT_DEV void tri(uint32_t i, float4 &a, float4 &b, float4 &c) const {
+    PT_DEV bool open(uint32_t ref, bool, v3, v3, float, uint32_t &first, uint32_t &cnt, uint32_t &cursor) const {
+        open_plain(ref, first, cnt, cursor); return true;
+    }
+    PT_DEV void tri(uint32_t cursor, uint32_t k, bool, float4 &a, float4 &b, float4 &c) const {
+        const uint32_t i = cursor + k;
         if (TRIS_IN_LDS) { lds_f4p p = tl + 3u * i; a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]); }
         else { glb_f4p p = tg + 3u * (size_t)i; a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]); }
+    }
+};
+
+PT_DEV bool slab(float bx0, float by0, float bz0, float bx1, float by1, float bz1, v3 o, v3 inv, float &tmin);
+
+// QUANTISED variant (large scenes, walked from global memory; fast_tree.hip::pt_quantize_tree builds the image):
+//   node, 32 B = 2 x uint4: per child three words of 16-bit plane numbers (lo.x | lo.y << 16, lo.z | hi.x << 16,
+//         hi.y | hi.z << 16) and its reference; plane k on axis a is fma(scale[a], k, origin[a]) — the child's exact box
+//         rounded OUTWARD to that grid. A box that contains a leaf's box passes whenever the leaf's own box passes (the
+//         slab predicate is monotone under containment), so the descent never loses a leaf the reference
+//         would test; it may reach a few it would not, and those stop at
+//   leaf stream (dwords): per leaf a header (exact lo.xyz, first triangle, exact hi.xyz, count) — the box the reference
+//         tests for this leaf, tested here when the leaf is opened, so the triangles tested are exactly the reference's —
+//         followed by 9 dwords per triangle (v0, e1, e2). A leaf reference is PT_REF_LEAF | dword offset of its header.
+// Half the bytes per node step and 25 % fewer per triangle: this variant waits on L2 / Infinity Cache, not on the ALUs.
+// Lanes that walk the tree as uploaded (`old`) read the exact 64-B image and the 48-B triangle images instead.
+typedef const __attribute__((address_space(1))) uint32_t *glb_u32p;
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) u4v *glb_u4p;
+struct QuantMem {
+    glb_u4p qn; glb_u32p ls; glb_f4p tp;
+    float ox, oy, oz, sx, sy, sz;
+    PT_DEV void node(uint32_t i, bool, Boxes &b) const {
+        const u4v l = qn[2u * (size_t)i], r = qn[2u * (size_t)i + 1u];
+        b.lx0 = fma1(sx, (float)(l.x & 0xFFFFu), ox); b.ly0 = fma1(sy, (float)(l.x >> 16), oy);
+        b.lz0 = fma1(sz, (float)(l.y & 0xFFFFu), oz); b.lx1 = fma1(sx, (float)(l.y >> 16), ox);
+        b.ly1 = fma1(sy, (float)(l.z & 0xFFFFu), oy); b.lz1 = fma1(sz, (float)(l.z >> 16), oz);
+        b.rx0 = fma1(sx, (float)(r.x & 0xFFFFu), ox); b.ry0 = fma1(sy, (float)(r.x >> 16), oy);
+        b.rz0 = fma1(sz, (float)(r.y & 0xFFFFu), oz); b.rx1 = fma1(sx, (float)(r.y >> 16), ox);
+        b.ry1 = fma1(sy, (float)(r.z & 0xFFFFu), oy); b.rz1 = fma1(sz, (float)(r.z >> 16), oz);
+        b.lref = l.w; b.rref = r.w;
+    }
+    PT_DEV bool open(uint32_t ref, bool plain, v3 o, v3 inv, float limit, uint32_t &first, uint32_t &cnt, uint32_t &cursor) const {
+        if (plain) { open_plain(ref, first, cnt, cursor); return true; }
+        const uint32_t off = ref & ~PT_REF_LEAF;
+        glb_u32p h = ls + off;
+        const float lx = __uint_as_float(h[0]), ly = __uint_as_float(h[1]), lz = __uint_as_float(h[2]);
+        first = h[3];
+        const float hx = __uint_as_float(h[4]), hy = __uint_as_float(h[5]), hz = __uint_as_float(h[6]);
+        cnt = h[7];
+        cursor = off + 8u;
+        float tl;
+        const bool pass = slab(lx, ly, lz, hx, hy, hz, o, inv, tl);       // the reference's own test of this leaf (pt.wgsl:266)
+        return pass & !(tl > limit);                                       // and the distance cull, against today's limit
+    }
+    PT_DEV void tri(uint32_t cursor, uint32_t k, bool plain, float4 &a, float4 &b, float4 &c) const {
+        if (plain) {
+            glb_f4p p = tp + 3u * (size_t)(cursor + k);
+            a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]);
+        } else {
+            glb_u32p p = ls + cursor + 9u * k;
+            a = make_float4(__uint_as_float(p[0]), __uint_as_float(p[1]), __uint_as_float(p[2]), 0.0f);
+            b = make_float4(__uint_as_float(p[3]), __uint_as_float(p[4]), __uint_as_float(p[5]), 0.0f);
+            c = make_float4(__uint_as_float(p[6]), __uint_as_float(p[7]), __uint_as_float(p[8]), 0.0f);
+        }
     }
 };
 
@@ -186,18 +264,7 @@ struct ShadowIO {
 // accesses coalesce) and goes on with an empty one; when the LDS part runs dry it takes the last 8 spilled entries
 // back. Deep trees then need no deeper LDS stacks — the occupancy of a depth-60 scene is that of a depth-14 one — and
 // the order in which nodes are visited, hence every result, is unchanged.
-// LEAF CULL AT POP (LC; closest hit, scenes of at most 4096 triangles): a filed leaf is tested later, often after a
-// nearer hit has been found. Its entry is (15-bit truncated entry distance, triangle count - 1, first triangle); when the
-// lane comes to test it, a leaf whose stored distance already exceeds the cull limit is dropped without its triangle
-// tests. The stored distance is max(tl, 0) rounded DOWN to 7 mantissa bits, so "stored > limit" implies "tl > limit" —
-// the very test a box gets in the node step (CULL), only against the limit of the moment the leaf is tested.
-constexpr uint32_t LC_MAX_TRIS = 4096u;
-PT_DEV uint32_t lc_pack(uint32_t ref, float tl) {
-    const uint32_t tb = __float_as_uint(max1(tl, 0.0f)) >> 16;                  // sign 0: 15 bits
-    return (tb << 17) | (((ref >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) << 12) | (ref & (LC_MAX_TRIS - 1u));
-}
-
-template <int MODE, bool CULL, int STACK, bool SPILL, bool LC, class Mem, class IO>
+template <int MODE, bool CULL, int STACK, bool SPILL, class Mem, class IO>
 PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t count, uint32_t gw,
                              uint32_t total_waves, uint32_t *stk, int stride, uint32_t *spill = nullptr,
                              uint32_t spill_lanes = 0) {
@@ -211,7 +278,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
     const uint32_t end = gw < ngroups ? ((ngroups - gw + total_waves - 1u) / total_waves) * 64u : 0u;
     uint32_t next = 0u;
     bool active = false, use_ref = false;
-    uint32_t slot = 0, cur = PT_REF_NONE, tri_i = 0, tri_e = 0;
+    uint32_t slot = 0, cur = PT_REF_NONE;
     // this lane's LDS entries as two pointers: the node stack grows up from `bot` (sp = next free entry), the list
     // of filed leaves grows down from `top` (lp = next free entry); STACK - used = (lp - sp) / stride + 1 entries free
     const lds_u32p bot = (lds_u32p)stk, top = bot + (STACK - 1) * stride;
@@ -233,7 +300,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                 io.fetch(slot, o, d, tlim);
                 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                 best.t = __builtin_inff(); best.u = best.v = 0.0f; best.tri = PT_REF_NONE;
-                sp = bot; lp = top; spn = 0u; cur = PT_REF_NONE; tri_i = tri_e = 0u;
+                sp = bot; lp = top; spn = 0u; cur = PT_REF_NONE;
                 limit = (ANY && CULL) ? cull_limit(tlim) : __builtin_inff();      // NaN for a directional light: never culls
                 const bool regular = __builtin_isfinite(inv.x) & __builtin_isfinite(inv.y) & __builtin_isfinite(inv.z) &
                                      (inv.x != 0.0f) & (inv.y != 0.0f) & (inv.z != 0.0f);
@@ -244,10 +311,8 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                          o, inv, tm)) {
                     active = true;
                     const uint32_t r = use_ref ? sc.ref_root_ref : sc.root_ref;
-                    if (r & PT_REF_LEAF) {
-                        tri_i = r & PT_LEAF_OFF_MASK;
-                        tri_e = tri_i + ((r >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) + 1u;
-                    } else cur = r;
+                    if (r & PT_REF_LEAF) { *lp = r; lp -= stride; }              // a one-leaf tree: file the root
+                    else cur = r;
                 } else {
                     io.finish(slot, best, false);
                 }
@@ -259,33 +324,32 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
 
         // two entries free (a step files at most two entries) — or, with SPILL, two free once the node entries are moved out
         const bool can_node = active & (cur != PT_REF_NONE) & ((int)room2(lp, sp, stride) | (int)(SPILL && (sp != bot) & room2(lp, bot, stride)));
-        const bool can_tri = active & ((tri_i < tri_e) | (lp != top));
+        const bool can_tri = active & (lp != top);
         const uint64_t bn = ballot(can_node), bt = ballot(can_tri);
         const bool run_tri = popc(bt) > popc(bn);
         bool occluded = false;
+        // Two copies of the streams: lanes that walk the uploaded tree (irregular rays, use_ref) read it from global memory
+        // in its own format; a wave holds such a lane almost never, and every other time it runs the copy without that
+        // per-step choice.
+        auto streams = [&](auto with_ref) {
+        constexpr bool REF = decltype(with_ref)::value;
+        const bool old = REF && use_ref;
         if (run_tri) {
             bool ct = can_tri;
 #pragma unroll 1
             for (int rep = 0; rep < LEAF_STEPS; rep++) {
                 if (ct) {
-                    if (tri_i == tri_e) {                               // next filed leaf
-                        lp += stride;
-                        const uint32_t ref = *lp;
-                        if (LC) {
-                            tri_i = ref & (LC_MAX_TRIS - 1u);
-                            const bool keep = !(__uint_as_float((ref >> 17) << 16) > limit);
-                            tri_e = keep ? tri_i + ((ref >> 12) & (PT_LEAF_MAX_TRIS - 1u)) + 1u : tri_i;
-                        } else {
-                            tri_i = ref & PT_LEAF_OFF_MASK;
-                            tri_e = tri_i + ((ref >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) + 1u;
-                        }
-                    }
-                    for (uint32_t ti = tri_i; ti < tri_e; ti++) {       // pt.wgsl:272-279
+                    lp += stride;                                       // next filed leaf
+                    uint32_t first, cnt, cursor;
+                    const bool plain = old;          // (a one-leaf tree is never quantised: its root reference is a plain one too)
+                    if (!m.open(*lp, plain, o, inv, (CULL && !ANY) ? limit : __builtin_inff(), first, cnt, cursor)) cnt = 0u;
+                    for (uint32_t k = 0; k < cnt; k++) {                // pt.wgsl:272-279
                         float4 a, b, c;
-                        m.tri(ti, a, b, c);
+                        m.tri(cursor, k, plain, a, b, c);
                         float u = 0.0f, v = 0.0f;
                         const float t = tri_test(xyz(a), xyz(b), xyz(c), o, d, u, v);
                         const bool hit = t > 0.0f;
+                        const uint32_t ti = first + k;
                         if (ANY) {
                             occluded = occluded | (hit & !(t >= tlim));
                         } else {
@@ -295,7 +359,6 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                             if (CULL) limit = better ? cull_limit(t) : limit;
                         }
                     }
-                    tri_i = tri_e;
                 }
                 if (rep + 1 < LEAF_STEPS) {
                     ct = ct & (lp != top) & !occluded;
@@ -303,12 +366,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                 }
             }
         } else {
-            // NODE_STEPS box-pair steps per vote: the vote and the bookkeeping around it cost about half a step.
-            // Two copies of the loop: lanes that walk the uploaded tree (irregular rays, use_ref) read their nodes from
-            // global memory; a wave holds such a lane almost never, and every other time it runs the copy without that
-            // per-step choice.
-            auto node_steps = [&](auto with_ref) {
-            constexpr bool REF = decltype(with_ref)::value;
+            // NODE_STEPS box-pair steps per vote: the vote and the bookkeeping around it cost about half a step
             bool cn = can_node;
 #pragma unroll
             for (int rep = 0; rep < NODE_STEPS; rep++) {
@@ -317,20 +375,22 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                         for (lds_u32p q = bot; q != sp; q += stride) { spill[(size_t)spn * spill_lanes] = *q; spn++; }
                         sp = bot;
                     }
-                    float4 a, b, c, r;
+                    Boxes nb;
                     if (REF && use_ref) {
+                        float4 a, b, c, r;
                         load_node((glb_f4p)sc.ref_wnodes + 4u * (size_t)cur, a, b, c, r);
+                        boxes_of(a, b, c, r, nb);
                     } else {
-                        m.node(cur, a, b, c, r);
+                        m.node(cur, false, nb);
                     }
                     float tl, tr;
-                    bool hl = slab(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, tl);
-                    bool hr = slab(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, tr);
+                    bool hl = slab(nb.lx0, nb.ly0, nb.lz0, nb.lx1, nb.ly1, nb.lz1, o, inv, tl);
+                    bool hr = slab(nb.rx0, nb.ry0, nb.rz0, nb.rx1, nb.ry1, nb.rz1, o, inv, tr);
                     if (CULL) { hl = hl & !(tl > limit); hr = hr & !(tr > limit); }
-                    const uint32_t lref = __float_as_uint(r.x), rref = __float_as_uint(r.y);
+                    const uint32_t lref = nb.lref, rref = nb.rref;
                     const bool ll = (lref & PT_REF_LEAF) != 0u, rl = (rref & PT_REF_LEAF) != 0u;
-                    if (hl & ll) { *lp = LC ? lc_pack(lref, tl) : lref; lp -= stride; }
-                    if (hr & rl) { *lp = LC ? lc_pack(rref, tr) : rref; lp -= stride; }
+                    if (hl & ll) { *lp = lref; lp -= stride; }
+                    if (hr & rl) { *lp = rref; lp -= stride; }
                     const bool il = hl & !ll, ir = hr & !rl;
                     const bool left_first = tl <= tr;
                     if (il & ir) { *sp = left_first ? rref : lref; sp += stride; cur = left_first ? lref : rref; }
@@ -354,30 +414,36 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                     if (popc(ballot(cn)) * NODE_KEEP < popc(bn)) break;
                 }
             }
-            };
-            if (sc.has_fast != 0u && ballot(use_ref & active) != 0ull) node_steps(std::true_type{});
-            else node_steps(std::false_type{});
         }
+        };
+        if (sc.has_fast != 0u && ballot(use_ref & active) != 0ull) streams(std::true_type{});
+        else streams(std::false_type{});
         // hang guard: an active lane that can take neither stream (cannot happen while STACK > tree depth) ends here
         const bool stuck = active & !can_node & !can_tri & ((bn | bt) == 0ull);
-        const bool done = active & (occluded | stuck | ((cur == PT_REF_NONE) & (lp == top) & (tri_i == tri_e)));
-        if (done) { io.finish(slot, best, occluded); active = false; cur = PT_REF_NONE; lp = top; tri_i = tri_e = 0u; }
+        const bool done = active & (occluded | stuck | ((cur == PT_REF_NONE) & (lp == top)));
+        if (done) { io.finish(slot, best, occluded); active = false; cur = PT_REF_NONE; lp = top; }
     }
 }
 
 // ------------------------------------------------------------------ global ----
 constexpr int GBLOCK = 256;
 
-template <int MODE, bool CULL, int STACK, class IO>
+template <int MODE, bool CULL, int STACK, bool QUANT, class IO>
 __global__ __launch_bounds__(GBLOCK) void k_trace_global(DevScene sc, IO io, const uint32_t *__restrict__ count_ptr,
                                                          uint32_t *__restrict__ spill) {
     __shared__ uint32_t stk[STACK * GBLOCK];
     const uint32_t count = *count_ptr;
     const uint32_t gw = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;       // consecutive groups -> different workgroups
     if (gw * 64u >= count) return;
-    GlobalMem m{(glb_f4p)sc.wnodes, (glb_f4p)sc.tripos};
-    trace_wave<MODE, CULL, STACK, true, false>(m, sc, io, count, gw, gridDim.x * (GBLOCK / 64), stk + threadIdx.x, GBLOCK,
-                                        spill + (size_t)blockIdx.x * GBLOCK + threadIdx.x, gridDim.x * GBLOCK);
+    uint32_t *sp = spill + (size_t)blockIdx.x * GBLOCK + threadIdx.x;
+    if constexpr (QUANT) {
+        QuantMem m{(glb_u4p)sc.qnodes, (glb_u32p)sc.leaf_stream, (glb_f4p)sc.tripos,
+                   sc.q_origin[0], sc.q_origin[1], sc.q_origin[2], sc.q_scale[0], sc.q_scale[1], sc.q_scale[2]};
+        trace_wave<MODE, CULL, STACK, true>(m, sc, io, count, gw, gridDim.x * (GBLOCK / 64), stk + threadIdx.x, GBLOCK, sp, gridDim.x * GBLOCK);
+    } else {
+        GlobalMem m{(glb_f4p)sc.wnodes, (glb_f4p)sc.tripos};
+        trace_wave<MODE, CULL, STACK, true>(m, sc, io, count, gw, gridDim.x * (GBLOCK / 64), stk + threadIdx.x, GBLOCK, sp, gridDim.x * GBLOCK);
+    }
 }
 
 // --------------------------------------------------------------------- LDS ----
@@ -391,7 +457,7 @@ __global__ __launch_bounds__(GBLOCK) void k_trace_global(DevScene sc, IO io, con
 // triangle and miss the LDS-resident triangles); ptmi_api picks per kernel.
 constexpr int LBLOCK = 1024;
 
-template <int MODE, bool CULL, int STACK, bool TRIS_IN_LDS, bool SPILL, bool LC, class IO>
+template <int MODE, bool CULL, int STACK, bool TRIS_IN_LDS, bool SPILL, class IO>
 __global__ __launch_bounds__(LBLOCK) void k_trace_lds(DevScene sc, IO io, const uint32_t *__restrict__ count_ptr,
                                                       uint32_t *__restrict__ spill) {
     extern __shared__ float4 smem[];
@@ -405,34 +471,24 @@ __global__ __launch_bounds__(LBLOCK) void k_trace_lds(DevScene sc, IO io, const 
     if (gw * 64u >= count) return;
     LdsMem<TRIS_IN_LDS> m{(lds_f4p)smem, (lds_f4p)(smem + nw), (glb_f4p)sc.tripos};
     uint32_t *stk = reinterpret_cast<uint32_t *>(smem + nw + nt) + threadIdx.x;
-    trace_wave<MODE, CULL, STACK, SPILL, LC>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk, LBLOCK,
+    trace_wave<MODE, CULL, STACK, SPILL>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk, LBLOCK,
                                          SPILL ? spill + (size_t)blockIdx.x * LBLOCK + threadIdx.x : nullptr, gridDim.x * LBLOCK);
 }
 
-#ifndef PT_LEAF_CULL
-#define PT_LEAF_CULL 1
-#endif
-template <int MODE, bool CULL, int STACK, bool TRIS, bool SPILL, bool LC, class IO>
-void launch_lds_lc(hipStream_t s, int wgs, size_t bytes, const DevScene &sc, const IO &io, const uint32_t *count, uint32_t *spill) {
+template <int MODE, bool CULL, int STACK, bool TRIS, bool SPILL = false, class IO>
+void launch_lds(hipStream_t s, int wgs, size_t bytes, const DevScene &sc, const IO &io, const uint32_t *count,
+                uint32_t *spill = nullptr) {
     // the default dynamic-LDS cap is 64 KB; raise it once per instantiation and device
     static std::atomic<uint64_t> raised{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     const uint64_t bit = 1ull << (dev & 63);
     if (!(raised.load(std::memory_order_relaxed) & bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_lds<MODE, CULL, STACK, TRIS, SPILL, LC, IO>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_lds<MODE, CULL, STACK, TRIS, SPILL, IO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         raised.fetch_or(bit, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((k_trace_lds<MODE, CULL, STACK, TRIS, SPILL, LC, IO>), dim3(wgs), dim3(LBLOCK), bytes, s, sc, io, count, spill);
-}
-template <int MODE, bool CULL, int STACK, bool TRIS, bool SPILL = false, class IO>
-void launch_lds(hipStream_t s, int wgs, size_t bytes, const DevScene &sc, const IO &io, const uint32_t *count,
-                uint32_t *spill = nullptr) {
-    // leaf cull at pop: closest hit with the distance cull on, and triangle indices that fit the packed entry
-    constexpr bool CAN_LC = PT_LEAF_CULL != 0 && MODE == MODE_EXTEND && CULL;
-    if (CAN_LC && sc.n_tris <= LC_MAX_TRIS) launch_lds_lc<MODE, CULL, STACK, TRIS, SPILL, CAN_LC>(s, wgs, bytes, sc, io, count, spill);
-    else launch_lds_lc<MODE, CULL, STACK, TRIS, SPILL, false>(s, wgs, bytes, sc, io, count, spill);
+    hipLaunchKernelGGL((k_trace_lds<MODE, CULL, STACK, TRIS, SPILL, IO>), dim3(wgs), dim3(LBLOCK), bytes, s, sc, io, count, spill);
 }
 
 // The persistent grid of the global variant is exactly the workgroups that are resident at once: every workgroup
@@ -443,15 +499,20 @@ void launch_lds(hipStream_t s, int wgs, size_t bytes, const DevScene &sc, const 
 // 6 is what the kernel's registers allow (4 waves per workgroup, 6 waves per SIMD); the occupancy query reports it.
 // (Before the stacks could spill, depth-29 grid_1m needed 32 LDS entries per lane: 4 workgroups per CU, 23.8 ms.)
 constexpr int GLOBAL_WGS_MAX = 8;          // what the spill area is sized for
-template <int MODE, bool CULL, class IO>
-void launch_global(hipStream_t s, int cus, const DevScene &sc, const IO &io, const uint32_t *count, uint32_t *spill) {
+template <int MODE, bool CULL, bool QUANT, class IO>
+void launch_global_q(hipStream_t s, int cus, const DevScene &sc, const IO &io, const uint32_t *count, uint32_t *spill) {
     static int per_cu = 0;
     if (per_cu == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace_global<MODE, CULL, 16, IO>, GBLOCK, 0) != hipSuccess || n < 1) n = 6;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace_global<MODE, CULL, 16, QUANT, IO>, GBLOCK, 0) != hipSuccess || n < 1) n = 6;
         per_cu = n < GLOBAL_WGS_MAX ? n : GLOBAL_WGS_MAX;
     }
-    hipLaunchKernelGGL((k_trace_global<MODE, CULL, 16, IO>), dim3(per_cu * cus), dim3(GBLOCK), 0, s, sc, io, count, spill);
+    hipLaunchKernelGGL((k_trace_global<MODE, CULL, 16, QUANT, IO>), dim3(per_cu * cus), dim3(GBLOCK), 0, s, sc, io, count, spill);
+}
+template <int MODE, bool CULL, class IO>
+void launch_global(hipStream_t s, int cus, const DevScene &sc, const IO &io, const uint32_t *count, uint32_t *spill, bool quant) {
+    if (quant && sc.qnodes) launch_global_q<MODE, CULL, true>(s, cus, sc, io, count, spill);
+    else launch_global_q<MODE, CULL, false>(s, cus, sc, io, count, spill);
 }
 
 template <int MODE, bool CULL, class IO>
@@ -472,7 +533,7 @@ void launch(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene
         if (cfg.stack_entries <= 16) launch_lds<MODE, CULL, 16, true>(s, cus, bytes, sc, io, count);
         else launch_lds<MODE, CULL, 32, true>(s, cus, bytes, sc, io, count);
     } else {
-        launch_global<MODE, CULL>(s, cus, sc, io, count, cfg.spill);
+        launch_global<MODE, CULL>(s, cus, sc, io, count, cfg.spill, cfg.quantized != 0);
     }
 }
 

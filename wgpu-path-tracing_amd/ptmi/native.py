@@ -12,7 +12,7 @@ from . import layout
 _LIB_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib")
 LIB_PATH = os.environ.get("PTMI_LIB") or os.path.join(_LIB_DIR, "libptmi.so")   # PTMI_LIB: A/B another build of the same ABI
 
-TRAVERSAL_AUTO, TRAVERSAL_GLOBAL, TRAVERSAL_LDS = 0, 1, 2
+TRAVERSAL_AUTO, TRAVERSAL_GLOBAL, TRAVERSAL_LDS, TRAVERSAL_GLOBAL_EXACT = 0, 1, 2, 3
 ATLAS_RGBA16F, ATLAS_RGBA32F = 1, 2
 
 # every symbol include/ptmi.h declares
@@ -22,6 +22,7 @@ EXPORTS = [
     "ptmi_synchronize", "ptmi_read_output", "ptmi_write_output", "ptmi_output_device_ptr",
     "ptmi_bind_output_device", "ptmi_set_stream", "ptmi_blit", "ptmi_get_stats", "ptmi_reset_stats",
     "ptmi_debug_raygen", "ptmi_debug_intersect", "ptmi_debug_occluded", "ptmi_debug_math", "ptmi_get_size",
+    "ptmi_debug_image_stats",
 ]
 ABI_VERSION = 2
 
@@ -91,6 +92,7 @@ def load():
         L.ptmi_set_stream.argtypes = [vp, vp]
         L.ptmi_blit.argtypes = [vp, vp, sz, vp, sz]
         L.ptmi_get_size.argtypes = [vp, vp, vp]
+        L.ptmi_debug_image_stats.argtypes = [vp, u32, vp, u32, vp]
         if L.ptmi_abi_version() != ABI_VERSION:
             raise PtmiError(-1, f"{LIB_PATH} has ABI {L.ptmi_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
         L.ptmi_get_stats.argtypes = [vp, vp]
@@ -105,6 +107,18 @@ def load():
 
 def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def image_stats(scene):
+    """Host-only report on the traversal image ptmi_upload_scene would build (include/ptmi.h: ptmi_debug_image_stats)."""
+    L = load()
+    out = (ctypes.c_double * 8)()
+    rc = L.ptmi_debug_image_stats(_p(scene.tris), len(scene.tris), _p(scene.nodes), len(scene.nodes), out)
+    if rc != 0:
+        raise PtmiError(rc, L.ptmi_last_error(None).decode())
+    keys = ("wide_nodes", "leaves", "depth", "quantised_nodes", "stream_dwords", "containment_violations",
+            "mean_area_growth", "stream_mismatches")
+    return dict(zip(keys, list(out)))
 
 
 class Context:
