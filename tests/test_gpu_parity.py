@@ -257,6 +257,29 @@ def test_tile_rows_and_traversal_modes(gpu_ctx, oracle, scene_factory):
     gpu_ctx.set_options(traversal=native.TRAVERSAL_AUTO, cull=1, tile_y0=0, tile_y1=0)
 
 
+@pytest.mark.parametrize("name", ["cornell", "cornell_spheres"])
+def test_ray_sort_is_invisible(gpu_ctx, oracle, scene_factory, name):
+    """ray_sort = 1 regroups each 1024-slot window of the queue by direction octant before the next traversal: other
+    waves, same rays — the image and the counters must not move by a bit. 200x130 pixels x 5 frames = 130 000 paths:
+    127 windows with a ragged last one, tiles that end inside a window."""
+    sc = scene_factory(name)
+    W, H, frames = 200, 130, 5
+    cam = layout.make_camera(W, H)
+    ref, ost = oracle.render(sc, cam, frames, max_bounces=8, do_mis=1)
+    gpu_ctx.upload_scene(sc)
+    for sort, fpb in ((1, 0), (1, 2), (0, 0)):
+        gpu_ctx.resize(W, H)
+        gpu_ctx.set_options(max_bounces=8, do_mis=1, tile_y0=0, tile_y1=0, tile_parts=0, frames_per_batch=fpb, cull=1, traversal=0,
+                            ray_sort=sort)
+        gpu_ctx.reset_stats()
+        gpu_ctx.dispatch(cam, frames)
+        got = gpu_ctx.read_output()
+        st = gpu_ctx.stats()
+        assert (st.segments, st.shadow_rays, st.paths) == (ost.segments, ost.shadow_rays, ost.paths)
+        assert_same_floats(got, ref, f"radiance (ray_sort {sort}, frames_per_batch {fpb})")
+    gpu_ctx.set_options(ray_sort=2, frames_per_batch=0)
+
+
 def test_errors_are_loud(gpu_ctx, scene_factory):
     from ptmi import native
     sc = scene_factory("cornell")

@@ -21,8 +21,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <future>
 #include <numeric>
-#include <unordered_map>
+#include <thread>
 
 namespace {
 
@@ -43,8 +45,9 @@ struct Builder {
     const std::vector<PtFastLeaf> &leaves;
     std::vector<uint32_t> idx;            // permutation of leaf ids; a node owns a contiguous range
     std::vector<float> cen[3];
-    std::vector<float4> &out;
-    uint32_t depth = 0;
+    std::vector<float4> &out;             // pre-sized: a tree over n leaves has n - 1 internal nodes
+    std::atomic<uint32_t> depth{0};
+    std::atomic<int> spare_threads{0};    // how many more subtree tasks may run beside their parent
 
     Box range_box(uint32_t s, uint32_t e) const {
         Box b; b.reset();
@@ -119,20 +122,30 @@ struct Builder {
         return pos;
     }
 
-    // returns the child reference of range [s, e) and writes its box; internal nodes are appended in preorder
-    uint32_t build(uint32_t s, uint32_t e, uint32_t d, Box &box) {
-        depth = std::max(depth, d);
+    // returns the child reference of range [s, e) and writes its box. Internal nodes are numbered in preorder: the node of
+    // [s, e) has index `me`, its left subtree (pos - s leaves, pos - s - 1 internal nodes) starts at me + 1, its right subtree
+    // at me + (pos - s). Subtrees own disjoint parts of idx and of out, so large ones are built by other threads.
+    uint32_t build(uint32_t s, uint32_t e, uint32_t d, uint32_t me, Box &box) {
+        uint32_t seen = depth.load(std::memory_order_relaxed);
+        while (seen < d && !depth.compare_exchange_weak(seen, d, std::memory_order_relaxed)) {}
         if (e - s == 1) {
             const PtFastLeaf &l = leaves[idx[s]];
             box.reset(); box.grow(l.mn, l.mx);
             return l.ref;
         }
-        const uint32_t me = (uint32_t)(out.size() / 4);
-        out.resize(out.size() + 4);
         const uint32_t pos = split(s, e, d);
         Box lb, rb;
-        const uint32_t lref = build(s, pos, d + 1, lb);
-        const uint32_t rref = build(pos, e, d + 1, rb);
+        uint32_t lref, rref;
+        if (e - s >= 16384 && spare_threads.fetch_sub(1, std::memory_order_relaxed) > 0) {
+            auto left = std::async(std::launch::async, [&] { return build(s, pos, d + 1, me + 1, lb); });
+            rref = build(pos, e, d + 1, me + (pos - s), rb);
+            lref = left.get();
+            spare_threads.fetch_add(1, std::memory_order_relaxed);
+        } else {
+            if (e - s >= 16384) spare_threads.fetch_add(1, std::memory_order_relaxed);       // undo the claim that found none
+            lref = build(s, pos, d + 1, me + 1, lb);
+            rref = build(pos, e, d + 1, me + (pos - s), rb);
+        }
         float fl, fr; std::memcpy(&fl, &lref, 4); std::memcpy(&fr, &rref, 4);
         float4 *w = &out[(size_t)me * 4];
         w[0] = make_float4(lb.mn[0], lb.mn[1], lb.mn[2], lb.mx[0]);
@@ -151,16 +164,18 @@ void pt_build_fast_tree(const std::vector<PtFastLeaf> &leaves, std::vector<float
     wnodes.clear();
     Builder b{leaves, {}, {}, wnodes};
     const uint32_t n = (uint32_t)leaves.size();
+    const unsigned hw = std::thread::hardware_concurrency();
+    b.spare_threads = (int)std::min(15u, hw > 1 ? hw - 1 : 0u);
     b.idx.resize(n);
     std::iota(b.idx.begin(), b.idx.end(), 0u);
     for (int k = 0; k < 3; k++) {
         b.cen[k].resize(n);
         for (uint32_t i = 0; i < n; i++) b.cen[k][i] = 0.5f * leaves[i].mn[k] + 0.5f * leaves[i].mx[k];
     }
-    wnodes.reserve((size_t)n * 4);
+    wnodes.assign(n > 1 ? (size_t)(n - 1) * 4 : 0, make_float4(0, 0, 0, 0));
     Box root;
-    root_ref = b.build(0, n, 1, root);
-    depth = b.depth;
+    root_ref = b.build(0, n, 1, 0, root);
+    depth = b.depth.load();
 }
 
 // ---- quantised image ------------------------------------------------------------------------------------------------
@@ -174,6 +189,7 @@ bool pt_quantize_tree(const std::vector<PtFastLeaf> &leaves, const std::vector<f
     for (const PtFastLeaf &l : leaves) {
         for (int k = 0; k < 3; k++) {
             if (!std::isfinite(l.mn[k]) || !std::isfinite(l.mx[k]) || l.mn[k] > l.mx[k]) return false;
+            if (std::fabs(l.mn[k]) > 1e15f || std::fabs(l.mx[k]) > 1e15f) return false;       // the node test's error bound assumes no overflow (traverse.hip)
             mn[k] = std::min(mn[k], l.mn[k]); mx[k] = std::max(mx[k], l.mx[k]);
         }
         n_tri_refs += l.weight;
@@ -206,44 +222,73 @@ bool pt_quantize_tree(const std::vector<PtFastLeaf> &leaves, const std::vector<f
         while (u < 65535u && std::fmaf(scale[k], (float)u, origin[k]) < v) u++;
         return u;
     };
-    // the leaf stream, in the order the leaves hang off the preorder nodes (neighbours in the tree are neighbours in memory)
-    std::unordered_map<uint32_t, const PtFastLeaf *> by_ref;
-    by_ref.reserve(leaves.size() * 2);
-    for (const PtFastLeaf &l : leaves) by_ref[l.ref] = &l;
-    stream.reserve(leaves.size() * 8 + n_tri_refs * 9);
-    auto emit_leaf = [&](uint32_t ref) -> uint32_t {
-        const PtFastLeaf &l = *by_ref.at(ref);
-        const uint32_t off = (uint32_t)stream.size();
-        const uint32_t first = ref & PT_LEAF_OFF_MASK, cnt = ((ref >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) + 1u;
-        auto put = [&](float f) { uint32_t u; std::memcpy(&u, &f, 4); stream.push_back(u); };
-        put(l.mn[0]); put(l.mn[1]); put(l.mn[2]); stream.push_back(first);
-        put(l.mx[0]); put(l.mx[1]); put(l.mx[2]); stream.push_back(cnt);
-        for (uint32_t t = first; t < first + cnt; t++)
-            for (int j = 0; j < 3; j++) { const float4 &v = tripos[3 * (size_t)t + j]; put(v.x); put(v.y); put(v.z); }
-        return PT_REF_LEAF | off;
-    };
+    // the leaf stream, in the order the leaves hang off the preorder nodes (neighbours in the tree are neighbours in memory).
+    // Pass 1 assigns every leaf child its place (sequential, two words per node); pass 2 fills nodes and stream in parallel.
+    const size_t n_tris = tripos.size() / 3;
+    std::vector<uint32_t> leaf_of_first(n_tris, 0xFFFFFFFFu);         // a leaf is identified by its first triangle
+    for (size_t i = 0; i < leaves.size(); i++) {
+        const uint32_t first = leaves[i].ref & PT_LEAF_OFF_MASK;
+        if (first >= n_tris) return false;
+        leaf_of_first[first] = (uint32_t)i;
+    }
+    std::vector<uint32_t> child_off(n_nodes * 2, 0u);
+    size_t total = 0;
+    for (size_t i = 0; i < n_nodes; i++) {
+        uint32_t refs[2]; std::memcpy(&refs[0], &wnodes[i * 4 + 3].x, 4); std::memcpy(&refs[1], &wnodes[i * 4 + 3].y, 4);
+        for (int c = 0; c < 2; c++)
+            if (refs[c] & PT_REF_LEAF) {
+                child_off[i * 2 + c] = (uint32_t)total;
+                total += 8 + 9 * (size_t)(((refs[c] >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) + 1u);
+            }
+    }
+    if (total >= (1ull << 31)) return false;
+    stream.assign(total, 0u);
     qnodes.resize(n_nodes * 2);
-    double growth = 0.0; size_t grown = 0;       // mean relative growth of the child boxes' surface area
     auto area = [](const float *l, const float *h) {
         const double x = (double)h[0] - l[0], y = (double)h[1] - l[1], z = (double)h[2] - l[2];
         return 2.0 * (x * y + y * z + z * x);
     };
-    for (size_t i = 0; i < n_nodes; i++) {
-        const float4 *w = &wnodes[i * 4];
-        const float lo[2][3] = {{w[0].x, w[0].y, w[0].z}, {w[1].z, w[1].w, w[2].x}};
-        const float hi[2][3] = {{w[0].w, w[1].x, w[1].y}, {w[2].y, w[2].z, w[2].w}};
-        uint32_t refs[2]; std::memcpy(&refs[0], &w[3].x, 4); std::memcpy(&refs[1], &w[3].y, 4);
-        for (int c = 0; c < 2; c++) {
-            uint32_t ql[3], qh[3];
-            for (int k = 0; k < 3; k++) { ql[k] = plane_lo(k, lo[c][k]); qh[k] = plane_hi(k, hi[c][k]); }
-            const uint32_t ref = (refs[c] & PT_REF_LEAF) ? emit_leaf(refs[c]) : refs[c];
-            qnodes[i * 2 + c] = make_uint4(ql[0] | (ql[1] << 16), ql[2] | (qh[0] << 16), qh[1] | (qh[2] << 16), ref);
-            float dl[3], dh[3];
-            for (int k = 0; k < 3; k++) { dl[k] = std::fmaf(scale[k], (float)ql[k], origin[k]); dh[k] = std::fmaf(scale[k], (float)qh[k], origin[k]); }
-            const double a0 = area(lo[c], hi[c]);
-            if (a0 > 0.0) { growth += std::min(area(dl, dh) / a0 - 1.0, 1e6); grown++; }
+    auto fill = [&](size_t i0, size_t i1, double &growth, size_t &grown, bool &ok) {
+        for (size_t i = i0; i < i1; i++) {
+            const float4 *w = &wnodes[i * 4];
+            const float lo[2][3] = {{w[0].x, w[0].y, w[0].z}, {w[1].z, w[1].w, w[2].x}};
+            const float hi[2][3] = {{w[0].w, w[1].x, w[1].y}, {w[2].y, w[2].z, w[2].w}};
+            uint32_t refs[2]; std::memcpy(&refs[0], &w[3].x, 4); std::memcpy(&refs[1], &w[3].y, 4);
+            for (int c = 0; c < 2; c++) {
+                uint32_t ql[3], qh[3];
+                for (int k = 0; k < 3; k++) { ql[k] = plane_lo(k, lo[c][k]); qh[k] = plane_hi(k, hi[c][k]); }
+                uint32_t ref = refs[c];
+                if (ref & PT_REF_LEAF) {
+                    const uint32_t first = ref & PT_LEAF_OFF_MASK, cnt = ((ref >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) + 1u;
+                    const uint32_t li = first < n_tris ? leaf_of_first[first] : 0xFFFFFFFFu;
+                    if (li == 0xFFFFFFFFu || leaves[li].ref != ref || (size_t)first + cnt > n_tris) { ok = false; continue; }
+                    const PtFastLeaf &l = leaves[li];
+                    uint32_t *h = &stream[child_off[i * 2 + c]];
+                    std::memcpy(h, l.mn, 12); h[3] = first; std::memcpy(h + 4, l.mx, 12); h[7] = cnt;
+                    for (uint32_t t = 0; t < cnt; t++)
+                        for (int j = 0; j < 3; j++) std::memcpy(h + 8 + 9 * t + 3 * j, &tripos[3 * (size_t)(first + t) + j], 12);
+                    ref = PT_REF_LEAF | child_off[i * 2 + c];
+                }
+                qnodes[i * 2 + c] = make_uint4(ql[0] | (ql[1] << 16), ql[2] | (qh[0] << 16), qh[1] | (qh[2] << 16), ref);
+                float dl[3], dh[3];
+                for (int k = 0; k < 3; k++) { dl[k] = std::fmaf(scale[k], (float)ql[k], origin[k]); dh[k] = std::fmaf(scale[k], (float)qh[k], origin[k]); }
+                const double a0 = area(lo[c], hi[c]);
+                if (a0 > 0.0) { growth += std::min(area(dl, dh) / a0 - 1.0, 1e6); grown++; }
+            }
         }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t n_thr = n_nodes < 65536 ? 1 : std::min<size_t>(16, hw ? hw : 1);
+    std::vector<double> g(n_thr, 0.0); std::vector<size_t> gn(n_thr, 0); std::vector<char> oks(n_thr, 1);
+    {
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < n_thr; t++)
+            pool.emplace_back([&, t] { bool ok = true; fill(n_nodes * t / n_thr, n_nodes * (t + 1) / n_thr, g[t], gn[t], ok); oks[t] = ok; });
+        bool ok = true; fill(0, n_nodes / n_thr, g[0], gn[0], ok); oks[0] = ok;
+        for (auto &th : pool) th.join();
     }
+    double growth = 0.0; size_t grown = 0;       // mean relative growth of the child boxes' surface area
+    for (size_t t = 0; t < n_thr; t++) { growth += g[t]; grown += gn[t]; if (!oks[t]) { qnodes.clear(); stream.clear(); return false; } }
     // One grid for the whole scene suits scenes whose boxes are not many orders of magnitude smaller than the scene.
     // Where they are (a chain of boxes shrinking geometrically), the rounded boxes would admit far more rays than the exact
     // ones: same results, much more work. Such scenes keep the exact image.

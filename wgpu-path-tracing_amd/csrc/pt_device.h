@@ -67,6 +67,8 @@ struct DevBand {
 struct ShadeParams {
     uint32_t bounce, max_bounces, do_mis;
     unsigned long long *stats;          // [1] += next-event samples counted but not traced (zero contribution)
+    uint64_t *octant_masks;             // ray_sort: per 64 slots the sign bits of the survivors' new direction, three arrays
+    uint32_t octant_stride;             //           octant_stride words apart (x, y, z); NULL: not wanted
 };
 
 enum { PT_VARIANT_GLOBAL = 1, PT_VARIANT_LDS = 2, PT_VARIANT_LDS_NODES = 3 };
@@ -102,7 +104,8 @@ uint32_t pt_compact_tile_slots(void);
 void pt_launch_compact(hipStream_t s, int tiles, const uint32_t *queue, const uint32_t *count,
                        const uint64_t *alive_mask, const uint64_t *shadow_mask, uint32_t *tile_sums,
                        uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_queue, uint32_t *shadow_count,
-                       unsigned long long *stats, uint32_t bounce, int do_scatter);
+                       unsigned long long *stats, uint32_t bounce, int do_scatter, const uint64_t *octant_masks = nullptr,
+                       uint32_t octant_stride = 0);
 void pt_launch_accumulate(hipStream_t s, int blocks, DevBand band, uint32_t frame0, uint32_t n_frames,
                           const float4 *L, float4 *out);
 void pt_launch_blit(hipStream_t s, int blocks, uint32_t W, uint32_t H, const float4 *color, float4 *out_f32,

@@ -51,7 +51,8 @@ struct ptmi_ctx {
     float4 *hits = nullptr;
     DevShadow sh{};
     uint32_t *queue[2] = {nullptr, nullptr}, *sq = nullptr;
-    uint64_t *alive = nullptr, *shadowm = nullptr;
+    uint64_t *alive = nullptr, *shadowm = nullptr, *octm = nullptr;   // octm: 3 x words (ray_sort)
+    size_t mask_words = 0;
     uint32_t *word_off = nullptr, *counts = nullptr;
     unsigned long long *d_stats = nullptr;
     uint32_t *d_spill = nullptr;          // node-stack overflow of the global traversal variant (128 MiB on 256 CUs, allocated by ptmi_create)
@@ -138,7 +139,7 @@ struct Timed {
 void free_batch(ptmi_ctx *c) {
     dfree(c->paths.O); dfree(c->paths.D); dfree(c->paths.T); dfree(c->paths.L);
     dfree(c->hits); dfree(c->sh.SO); dfree(c->sh.SD); dfree(c->sh.SC);
-    dfree(c->queue[0]); dfree(c->queue[1]); dfree(c->sq); dfree(c->alive); dfree(c->shadowm); dfree(c->word_off); dfree(c->d_occ);
+    dfree(c->queue[0]); dfree(c->queue[1]); dfree(c->sq); dfree(c->alive); dfree(c->shadowm); dfree(c->octm); dfree(c->word_off); dfree(c->d_occ);
     c->cap = 0;
 }
 
@@ -157,6 +158,7 @@ int ensure_capacity(ptmi_ctx *c, size_t n) {
     HIP_TRY(c, hipMalloc(&c->queue[0], cap * 4)); HIP_TRY(c, hipMalloc(&c->queue[1], cap * 4));
     HIP_TRY(c, hipMalloc(&c->sq, cap * 4));
     HIP_TRY(c, hipMalloc(&c->alive, words * 8)); HIP_TRY(c, hipMalloc(&c->shadowm, words * 8));
+    HIP_TRY(c, hipMalloc(&c->octm, 3 * words * 8)); c->mask_words = words;
     HIP_TRY(c, hipMalloc(&c->word_off, 2 * tiles * 4));
     HIP_TRY(c, hipMalloc(&c->d_occ, cap));
     c->cap = cap;
@@ -269,8 +271,12 @@ int build_image(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_
         b.tripos[3 * (size_t)i + 1] = make_float4(t.v1[0] - t.v0[0], t.v1[1] - t.v0[1], t.v1[2] - t.v0[2], 0.0f);
         b.tripos[3 * (size_t)i + 2] = make_float4(t.v2[0] - t.v0[0], t.v2[1] - t.v0[1], t.v2[2] - t.v0[2], 0.0f);
     }
-    if (!b.fast_wnodes.empty() && !pt_quantize_tree(leaves, b.fast_wnodes, b.tripos, b.qnodes, b.leaf_stream, b.q_origin, b.q_scale)) {
-        b.qnodes.clear(); b.leaf_stream.clear();
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        if (!b.fast_wnodes.empty() && !pt_quantize_tree(leaves, b.fast_wnodes, b.tripos, b.qnodes, b.leaf_stream, b.q_origin, b.q_scale)) {
+            b.qnodes.clear(); b.leaf_stream.clear();
+        }
+        b.tree_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     return PTMI_OK;
 }
@@ -533,6 +539,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     const int blocks = c->n_cu * 8;
     const int tiles = (int)(c->cap / pt_compact_tile_slots() + 1);
     const uint32_t maxb = c->opt.max_bounces;
+    const bool sort = c->opt.ray_sort == 1;          // 2 (library default) = off: measured, profiles/README.md
     const bool t1 = c->opt.timing >= 1, t2 = c->opt.timing >= 2, t3 = c->opt.timing >= 3;
     {
         Timed td(c, 0, t1);
@@ -544,14 +551,16 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
             for (uint32_t b = 0; b < maxb; b++) {
                 const uint32_t *q = b == 0 ? nullptr : c->queue[cur];      // bounce 0: slot i holds path i
                 { Timed t(c, 1, t2); pt_launch_extend(c->stream, blocks, cfg, c->sc, c->paths, q, &c->counts[b], c->hits); }
-                { Timed t(c, 2, t3); pt_launch_shade(c->stream, blocks, c->sc, c->paths, q, &c->counts[b], c->hits, c->sh,
-                                                     c->alive, c->shadowm, ShadeParams{b, maxb, c->opt.do_mis, c->d_stats}); }
-                const bool nee = c->opt.do_mis && c->sc.n_lights > 0;
                 const bool last = b + 1 == maxb;
+                uint64_t *octm = (sort && !last) ? c->octm : nullptr;
+                { Timed t(c, 2, t3); pt_launch_shade(c->stream, blocks, c->sc, c->paths, q, &c->counts[b], c->hits, c->sh,
+                                                     c->alive, c->shadowm,
+                                                     ShadeParams{b, maxb, c->opt.do_mis, c->d_stats, octm, (uint32_t)c->mask_words}); }
+                const bool nee = c->opt.do_mis && c->sc.n_lights > 0;
                 { Timed t(c, 5, t3);
                   pt_launch_compact(c->stream, tiles, q, &c->counts[b], c->alive, nee ? c->shadowm : nullptr,
                                     c->word_off, c->queue[cur ^ 1], &c->counts[b + 1], c->sq, &c->counts[kShadowCount],
-                                    c->d_stats, b, last ? 0 : 1); }
+                                    c->d_stats, b, last ? 0 : 1, octm, (uint32_t)c->mask_words); }
                 if (nee) {
                     Timed t(c, 3, t3);
                     pt_launch_shadow(c->stream, blocks, cfg_shadow, c->sc, c->paths, c->sh, c->sq, &c->counts[kShadowCount], nullptr);

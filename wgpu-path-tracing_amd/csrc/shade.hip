@@ -284,6 +284,7 @@ __global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const
     for (uint32_t base = blockIdx.x * SBLOCK; base < count; base += gridDim.x * SBLOCK) {
         const uint32_t i = base + threadIdx.x;
         bool alive = false, shadow = false, skipped = false;
+        bool neg_x = false, neg_y = false, neg_z = false;          // ray_sort: octant of the new direction
         if (i < count) {
             const uint32_t p = queue ? queue[i] : i;
             const float4 h4 = hits[i];
@@ -338,6 +339,7 @@ __global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const
                             else thr = vdiv3(thr, pr);
                         }
                         if (alive && sp.bounce + 1u < sp.max_bounces) {
+                            neg_x = nd.x < 0.0f; neg_y = nd.y < 0.0f; neg_z = nd.z < 0.0f;
                             P.O[p] = make_float4(no.x, no.y, no.z, __uint_as_float(rng));
                             P.D[p] = make_float4(nd.x, nd.y, nd.z, 0.0f);
                             P.T[p] = make_float4(thr.x, thr.y, thr.z, 0.0f);
@@ -351,6 +353,14 @@ __global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const
             alive_mask[i >> 6] = am;
             shadow_mask[i >> 6] = sm;
             n_skipped += (uint32_t)__popcll(zm);
+        }
+        if (sp.octant_masks) {
+            const uint64_t bx = __ballot(neg_x), by = __ballot(neg_y), bz = __ballot(neg_z);
+            if ((threadIdx.x & 63u) == 0u && i < count) {
+                sp.octant_masks[i >> 6] = bx;
+                sp.octant_masks[sp.octant_stride + (i >> 6)] = by;
+                sp.octant_masks[2u * sp.octant_stride + (i >> 6)] = bz;
+            }
         }
     }
     if (n_skipped) atomicAdd(&sp.stats[1], (unsigned long long)n_skipped);

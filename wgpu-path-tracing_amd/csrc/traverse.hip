@@ -89,8 +89,19 @@ PT_DEV void open_plain(uint32_t ref, uint32_t &first, uint32_t &cnt, uint32_t &c
     first = ref & PT_LEAF_OFF_MASK; cnt = ((ref >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) + 1u; cursor = first;
 }
 
+PT_DEV bool slab(float bx0, float by0, float bz0, float bx1, float by1, float bz1, v3 o, v3 inv, float &tmin);
+
 struct GlobalMem {
     glb_f4p wn, tp;
+    struct RayK {};
+    PT_DEV static bool in_range(v3, v3) { return true; }
+    PT_DEV void prep(v3, v3, RayK &) const {}
+    PT_DEV void test(uint32_t i, v3 o, v3 inv, const RayK &, bool &hl, bool &hr, float &tl, float &tr, uint32_t &lref, uint32_t &rref) const {
+        Boxes nb; node(i, false, nb);
+        hl = slab(nb.lx0, nb.ly0, nb.lz0, nb.lx1, nb.ly1, nb.lz1, o, inv, tl);
+        hr = slab(nb.rx0, nb.ry0, nb.rz0, nb.rx1, nb.ry1, nb.rz1, o, inv, tr);
+        lref = nb.lref; rref = nb.rref;
+    }
     PT_DEV void node(uint32_t i, bool, Boxes &o) const { float4 a, b, c, r; load_node(wn + 4u * (size_t)i, a, b, c, r); boxes_of(a, b, c, r, o); }
     PT_DEV bool open(uint32_t ref, bool, v3, v3, float, uint32_t &first, uint32_t &cnt, uint32_t &cursor) const {
         open_plain(ref, first, cnt, cursor); return true;
@@ -105,6 +116,15 @@ struct GlobalMem {
 template <bool TRIS_IN_LDS>
 struct LdsMem {
     lds_f4p wn, tl; glb_f4p tg;
+    struct RayK {};
+    PT_DEV static bool in_range(v3, v3) { return true; }
+    PT_DEV void prep(v3, v3, RayK &) const {}
+    PT_DEV void test(uint32_t i, v3 o, v3 inv, const RayK &, bool &hl, bool &hr, float &tl, float &tr, uint32_t &lref, uint32_t &rref) const {
+        Boxes nb; node(i, false, nb);
+        hl = slab(nb.lx0, nb.ly0, nb.lz0, nb.lx1, nb.ly1, nb.lz1, o, inv, tl);
+        hr = slab(nb.rx0, nb.ry0, nb.rz0, nb.rx1, nb.ry1, nb.rz1, o, inv, tr);
+        lref = nb.lref; rref = nb.rref;
+    }
     PT_DEV void node(uint32_t i, bool, Boxes &o) const {
         lds_f4p p = wn + 4u * i;
         boxes_of(as_f4(p[0]), as_f4(p[1]), as_f4(p[2]), as_f4(p[3]), o);
@@ -119,8 +139,6 @@ struct LdsMem {
     }
 };
 
-PT_DEV bool slab(float bx0, float by0, float bz0, float bx1, float by1, float bz1, v3 o, v3 inv, float &tmin);
-
 // QUANTISED variant (large scenes, walked from global memory; fast_tree.hip::pt_quantize_tree builds the image):
 //   node, 32 B = 2 x uint4: per child three words of 16-bit plane numbers (lo.x | lo.y << 16, lo.z | hi.x << 16,
 //         hi.y | hi.z << 16) and its reference; plane k on axis a is fma(scale[a], k, origin[a]) — the child's exact box
@@ -130,14 +148,54 @@ PT_DEV bool slab(float bx0, float by0, float bz0, float bx1, float by1, float bz
 //   leaf stream (dwords): per leaf a header (exact lo.xyz, first triangle, exact hi.xyz, count) — the box the reference
 //         tests for this leaf, tested here when the leaf is opened, so the triangles tested are exactly the reference's —
 //         followed by 9 dwords per triangle (v0, e1, e2). A leaf reference is PT_REF_LEAF | dword offset of its header.
-// Half the bytes per node step and 25 % fewer per triangle: this variant waits on L2 / Infinity Cache, not on the ALUs.
+// Half the bytes per node step and 25 % fewer per triangle: this variant waits on L2 / Infinity Cache as much as on the ALUs.
 // Lanes that walk the tree as uploaded (`old`) read the exact 64-B image and the 48-B triangle images instead.
+//
+// The node test needs no particular arithmetic, only a guarantee: it must pass whenever the contract's slab test passes on
+// the decoded box (which contains the leaf boxes below it, so by monotonicity: whenever a leaf's own test passes). It
+// therefore evaluates the planes' ray distances in one fused step, t~ = fma(k, scale * inv, (origin - o) * inv), and widens
+// the resulting interval by delta, an upper bound of |t~ - t_contract| for every plane of the grid:
+//   t_contract = fl(fl(p - o) * inv) with p = fl(scale * k + origin);  both differ from the real (scale k + origin - o) inv by
+//   rounding errors proportional to |inv| (k scale + |origin| + |o|); adding them up (six roundings, u = 2^-24) gives
+//   |t~ - t_contract| <= 6.1 u |inv| (65535 scale + |origin| + |o|).  delta is that with 16.8 u (1e-6) instead of 6.1 u, the
+//   maximum over the three axes, plus 1e-37 for products that underflow.
+// Overflow (inf - inf = NaN would void the argument) cannot occur: rays with a component of 1/d beyond 1e18 or an origin
+// beyond 1e15 count as irregular (they walk the uploaded tree with the contract's own test), and a scene that reaches beyond
+// 1e15 is not quantised (fast_tree.hip).
 typedef const __attribute__((address_space(1))) uint32_t *glb_u32p;
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) u4v *glb_u4p;
 struct QuantMem {
     glb_u4p qn; glb_u32p ls; glb_f4p tp;
     float ox, oy, oz, sx, sy, sz;
+    struct RayK { float kx, ky, kz, cx, cy, cz, delta; };
+    PT_DEV static bool in_range(v3 o, v3 inv) {
+        return (__builtin_fabsf(inv.x) <= 1e18f) & (__builtin_fabsf(inv.y) <= 1e18f) & (__builtin_fabsf(inv.z) <= 1e18f) &
+               (__builtin_fabsf(o.x) <= 1e15f) & (__builtin_fabsf(o.y) <= 1e15f) & (__builtin_fabsf(o.z) <= 1e15f);
+    }
+    PT_DEV void prep(v3 o, v3 inv, RayK &r) const {
+        r.kx = sx * inv.x; r.ky = sy * inv.y; r.kz = sz * inv.z;
+        r.cx = (ox - o.x) * inv.x; r.cy = (oy - o.y) * inv.y; r.cz = (oz - o.z) * inv.z;
+        const float dx = __builtin_fabsf(inv.x) * (65535.0f * sx + __builtin_fabsf(ox) + __builtin_fabsf(o.x));
+        const float dy = __builtin_fabsf(inv.y) * (65535.0f * sy + __builtin_fabsf(oy) + __builtin_fabsf(o.y));
+        const float dz = __builtin_fabsf(inv.z) * (65535.0f * sz + __builtin_fabsf(oz) + __builtin_fabsf(o.z));
+        r.delta = max1(max1(dx, dy), dz) * 1e-6f + 1e-37f;
+    }
+    PT_DEV static bool qslab(uint32_t w0, uint32_t w1, uint32_t w2, const RayK &r, float &tmin) {
+        // words: lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16
+        const float t1x = fma1((float)(w0 & 0xFFFFu), r.kx, r.cx), t2x = fma1((float)(w1 >> 16), r.kx, r.cx);
+        const float t1y = fma1((float)(w0 >> 16), r.ky, r.cy), t2y = fma1((float)(w2 & 0xFFFFu), r.ky, r.cy);
+        const float t1z = fma1((float)(w1 & 0xFFFFu), r.kz, r.cz), t2z = fma1((float)(w2 >> 16), r.kz, r.cz);
+        tmin = max1(max1(min1(t1x, t2x), min1(t1y, t2y)), min1(t1z, t2z)) - r.delta;
+        const float tmax = min1(min1(max1(t1x, t2x), max1(t1y, t2y)), max1(t1z, t2z)) + r.delta;
+        return tmax >= tmin && tmax >= 0.0f;
+    }
+    PT_DEV void test(uint32_t i, v3, v3, const RayK &r, bool &hl, bool &hr, float &tl, float &tr, uint32_t &lref, uint32_t &rref) const {
+        const u4v l = qn[2u * (size_t)i], rr = qn[2u * (size_t)i + 1u];
+        hl = qslab(l.x, l.y, l.z, r, tl);
+        hr = qslab(rr.x, rr.y, rr.z, r, tr);
+        lref = l.w; rref = rr.w;
+    }
     PT_DEV void node(uint32_t i, bool, Boxes &b) const {
         const u4v l = qn[2u * (size_t)i], r = qn[2u * (size_t)i + 1u];
         b.lx0 = fma1(sx, (float)(l.x & 0xFFFFu), ox); b.ly0 = fma1(sy, (float)(l.x >> 16), oy);
@@ -286,6 +344,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
     uint32_t spn = 0;                       // SPILL: entries of this lane in the spill area
     v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), inv = mk3(0, 0, 0);
     float tlim = 0.0f, limit = __builtin_inff();
+    typename Mem::RayK rk{};
     Hit best; best.t = __builtin_inff(); best.u = best.v = 0.0f; best.tri = PT_REF_NONE;
 
     for (;;) {
@@ -303,8 +362,9 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                 sp = bot; lp = top; spn = 0u; cur = PT_REF_NONE;
                 limit = (ANY && CULL) ? cull_limit(tlim) : __builtin_inff();      // NaN for a directional light: never culls
                 const bool regular = __builtin_isfinite(inv.x) & __builtin_isfinite(inv.y) & __builtin_isfinite(inv.z) &
-                                     (inv.x != 0.0f) & (inv.y != 0.0f) & (inv.z != 0.0f);
+                                     (inv.x != 0.0f) & (inv.y != 0.0f) & (inv.z != 0.0f) & Mem::in_range(o, inv);
                 use_ref = sc.has_fast != 0u && !regular;
+                m.prep(o, inv, rk);
                 float tm;
                 if (sc.root_ref != PT_REF_NONE &&
                     slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2],
@@ -375,19 +435,20 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                         for (lds_u32p q = bot; q != sp; q += stride) { spill[(size_t)spn * spill_lanes] = *q; spn++; }
                         sp = bot;
                     }
-                    Boxes nb;
+                    float tl, tr;
+                    bool hl, hr;
+                    uint32_t lref, rref;
                     if (REF && use_ref) {
                         float4 a, b, c, r;
                         load_node((glb_f4p)sc.ref_wnodes + 4u * (size_t)cur, a, b, c, r);
-                        boxes_of(a, b, c, r, nb);
+                        Boxes nb; boxes_of(a, b, c, r, nb);
+                        hl = slab(nb.lx0, nb.ly0, nb.lz0, nb.lx1, nb.ly1, nb.lz1, o, inv, tl);
+                        hr = slab(nb.rx0, nb.ry0, nb.rz0, nb.rx1, nb.ry1, nb.rz1, o, inv, tr);
+                        lref = nb.lref; rref = nb.rref;
                     } else {
-                        m.node(cur, false, nb);
+                        m.test(cur, o, inv, rk, hl, hr, tl, tr, lref, rref);
                     }
-                    float tl, tr;
-                    bool hl = slab(nb.lx0, nb.ly0, nb.lz0, nb.lx1, nb.ly1, nb.lz1, o, inv, tl);
-                    bool hr = slab(nb.rx0, nb.ry0, nb.rz0, nb.rx1, nb.ry1, nb.rz1, o, inv, tr);
                     if (CULL) { hl = hl & !(tl > limit); hr = hr & !(tr > limit); }
-                    const uint32_t lref = nb.lref, rref = nb.rref;
                     const bool ll = (lref & PT_REF_LEAF) != 0u, rl = (rref & PT_REF_LEAF) != 0u;
                     if (hl & ll) { *lp = lref; lp -= stride; }
                     if (hr & rl) { *lp = rref; lp -= stride; }
@@ -428,8 +489,16 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
 // ------------------------------------------------------------------ global ----
 constexpr int GBLOCK = 256;
 
+#ifndef PT_GLOBAL_WAVES
+#define PT_GLOBAL_WAVES 0          /* > 0: ask the register allocator for at least that many waves per SIMD */
+#endif
+#if PT_GLOBAL_WAVES > 0
+#define PT_GLOBAL_ATTR __attribute__((amdgpu_waves_per_eu(PT_GLOBAL_WAVES)))
+#else
+#define PT_GLOBAL_ATTR
+#endif
 template <int MODE, bool CULL, int STACK, bool QUANT, class IO>
-__global__ __launch_bounds__(GBLOCK) void k_trace_global(DevScene sc, IO io, const uint32_t *__restrict__ count_ptr,
+__global__ __launch_bounds__(GBLOCK) PT_GLOBAL_ATTR void k_trace_global(DevScene sc, IO io, const uint32_t *__restrict__ count_ptr,
                                                          uint32_t *__restrict__ spill) {
     __shared__ uint32_t stk[STACK * GBLOCK];
     const uint32_t count = *count_ptr;
