@@ -102,3 +102,59 @@ def test_camera_methods_match_a_float64_model():
     for name, want in (("position", pos), ("forward", f), ("right", r), ("up", u)):
         assert np.allclose(cam[name], want, rtol=0, atol=1e-12), name
     assert abs(np.dot(cam["forward"], cam["right"])) < 1e-12 and abs(np.linalg.norm(cam["up"]) - 1) < 1e-12
+
+
+GPU_SCRIPT = """
+var EventEmitter = require('events'), fs = require('fs'), host = require('./renderer');
+var a = JSON.parse(process.argv[1]), src = new EventEmitter();
+host.setupRenderer({ width: a.W, height: a.H, input: src, model: a.scene }).then(function (r) {
+  for (var i = 0; i < 3; i++) r.renderFrame();                 // three frames at the reference's default pose
+  var before = r.frameIndex;
+  src.emit('keydown', { key: 'w' }); src.emit('keydown', { key: 'd' });
+  r.controller.update(0.25);                                   // -> moveCamera twice -> resetOutputBuffer (renderer.ts:357-366)
+  src.emit('keyup', { key: 'w' }); src.emit('keyup', { key: 'd' });
+  src.emit('mousemove', { movementX: 40, movementY: -10 });
+  r.controller.update(0.25);                                   // -> rotateCamera -> resetOutputBuffer
+  var running = r.timer !== null;                              // the reference restarts its frame loop on a move
+  r.stop();                                                    // ... stepped by hand here
+  var afterMove = r.frameIndex;
+  r.renderFrame(); r.renderFrame();
+  fs.writeFileSync(a.out, Buffer.from(r.readOutput().buffer));
+  console.log(JSON.stringify({ before: before, afterMove: afterMove, running: running, frameIndex: r.frameIndex, camera: r.camera }));
+  r.destroy();
+}).catch(function (e) { console.error(String(e && e.stack || e)); process.exit(1); });
+"""
+
+
+@pytest.mark.gpu
+def test_scripted_input_moves_the_camera_and_restarts_accumulation_on_the_gpu(tmp_path):
+    """The preview loop of SURVEY.md §8f row 4 on the device: scripted key / mouse events -> Controller.update ->
+    moveCamera / rotateCamera -> the frame index returns to 0 (src/renderer/renderer.ts:357-366) -> the next frames
+    overwrite the buffer (pt.wgsl:754-761), so the image is the oracle's render of frames 0..1 from the MOVED camera,
+    bit for bit, whatever was accumulated before the move."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import Oracle
+    from ptmi import layout, scene_io, scenes
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "wgpu-path-tracing_amd"), "all"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(HOST, "addon")], stdout=subprocess.DEVNULL)
+    sc = scenes.make("cornell")
+    scene_io.save_ptscene(sc, str(tmp_path / "cornell.ptscene"))
+    W, H = 112, 80
+    args = {"W": W, "H": H, "scene": str(tmp_path / "cornell.ptscene"), "out": str(tmp_path / "o.f32")}
+    res = json.loads(subprocess.check_output([NODE, "-e", GPU_SCRIPT, json.dumps(args)], cwd=HOST, text=True).strip().splitlines()[-1])
+    assert res["before"] == 3 and res["afterMove"] == 0 and res["frameIndex"] == 2 and res["running"] is True
+    cam = res["camera"]
+    # the pose the events lead to: 0.5 forward and 0.5 right (MOVE_SPEED 2 x 0.25 s), then yaw / pitch by the mouse deltas
+    assert np.allclose(cam["position"], [0.5, 1.0, 2.3])
+    rot = math.pi / 18 * 0.25
+    yaw, pitch = 40 * -rot, 10 * rot
+    f = np.array([-math.sin(yaw) * math.cos(pitch), math.sin(pitch), -math.cos(yaw) * math.cos(pitch)])
+    assert np.allclose(cam["forward"], f, atol=1e-12)
+    c = layout.make_camera(W, H, position=cam["position"], forward=cam["forward"], right=cam["right"], up=cam["up"],
+                           fov=cam["fov"], aspect=cam["aspect"], aperture=cam["aperture"], focus_distance=cam["focusDistance"])
+    ref, _ = Oracle().render(sc, c, 2)
+    got = np.fromfile(tmp_path / "o.f32", np.float32).reshape(H, W, 4)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    still, _ = Oracle().render(sc, layout.make_camera(W, H), 2)
+    assert not np.array_equal(ref, still)                      # the move is visible

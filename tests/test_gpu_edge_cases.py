@@ -167,3 +167,70 @@ def test_deep_tree_spills_the_node_stack(gpu_ctx, oracle, scene_factory):
             assert np.array_equal(t.view(np.uint32), t_ref.view(np.uint32)) and np.array_equal(u.view(np.uint32), u_ref.view(np.uint32))
             assert np.array_equal(gpu_ctx.debug_occluded(o, d, dist), occ_ref)
     gpu_ctx.set_options(keep_reference_tree=0, traversal=native.TRAVERSAL_AUTO)
+
+
+def test_distance_cull_against_grazing_triangles(gpu_ctx, oracle):
+    """The one freedom of the traversal that is not exact arithmetic: cull = 1 skips a box whose
+    entry distance exceeds best * 1.001 + 1e-4 — slack for the rounding of a triangle's own t. That slack covers every
+    triangle whose computed t is within 0.1 % of its true distance; Moller-Trumbore (pt.wgsl:128-158) loses that accuracy
+    only for rays within ~1e-4 rad of a large triangle's plane, where t = (s.N)/(d.N) divides two cancelling sums.
+    This scene builds exactly that: a blocker 50 units away and, behind it, a 20-unit triangle pair whose plane the rays
+    graze (the oracle takes the pair as the nearest hit on ~100 of the 20 000 grazing rays, at computed distances below 49.9
+    for a surface that starts at 50.5; on ~40 of them the pair's leaf box lies beyond the cull limit once the blocker is
+    found). Checked:
+      * cull = 0 (the reference's own leaf set) equals the oracle bit for bit on every ray, grazing or not;
+      * cull = 1 equals it too on every ray that meets the planes at more than 1e-2 rad;
+      * where cull = 1 differs on a grazing ray, the oracle's pick is the grazing triangle with a computed t that is off
+        its true distance by more than the slack — the documented caveat, nothing else."""
+    def grid(corner, du, dv, nu, nv, normal):
+        c, du, dv = (np.array(x, np.float64) for x in (corner, du, dv))
+        return [scenes._quad(c + du * i + dv * j, c + du * (i + 1) + dv * j, c + du * (i + 1) + dv * (j + 1), c + du * i + dv * (j + 1),
+                             normal, 0) for i in range(nu) for j in range(nv)]
+    parts = grid((0, -1, -1), (0, 0.5, 0), (0, 0, 0.5), 4, 4, (-1, 0, 0))                    # blocker: 32 triangles in the plane x = 0
+    # the grazed pair: a 20 x 2 strip, so that (even rotated) its box starts behind the blocker for rays along it
+    parts.append(scenes._quad((0.5, 0.3, -1), (20.5, 0.3, -1), (20.5, 0.3, 1), (0.5, 0.3, 1), (0, -1, 0), 0))
+    parts += grid((30, -20, -20), (0, 4, 0), (0, 0, 4), 10, 10, (-1, 0, 0))                  # far wall: 200 triangles
+    # nothing axis-aligned: with axis-aligned triangles most products in Moller-Trumbore are exact zeros and nothing cancels
+    def rot(ax, a):
+        c, s_ = np.cos(a), np.sin(a)
+        return np.array([[[1, 0, 0], [0, c, -s_], [0, s_, c]], [[c, 0, s_], [0, 1, 0], [-s_, 0, c]], [[c, -s_, 0], [s_, c, 0], [0, 0, 1]]][ax])
+    R = rot(2, 0.5) @ rot(0, 0.35) @ rot(1, 0.2)
+    for t in parts:
+        for k in ("v0", "v1", "v2", "n0", "n1", "n2"):
+            t[k] = (t[k].astype(np.float64) @ R.T).astype(np.float32)
+    sc = scenes._finish("grazing", parts, [scenes._material()])
+    big_ids = np.flatnonzero(np.isclose(sc.tris["v0"].astype(np.float64) @ R, 0.3, atol=1e-5)[:, 1]
+                             & np.isclose(sc.tris["v1"].astype(np.float64) @ R, 0.3, atol=1e-5)[:, 1]
+                             & np.isclose(sc.tris["v2"].astype(np.float64) @ R, 0.3, atol=1e-5)[:, 1])
+    assert len(big_ids) == 2
+    rng = np.random.default_rng(5)
+    n = 40_000
+    theta = np.where(np.arange(n) % 2 == 0, 10.0 ** rng.uniform(-7.5, -4, n), 10.0 ** rng.uniform(-2, -0.6, n))   # grazing / control
+    xh = rng.uniform(1.0, 20.0, n)                      # where the ray would meet the grazed plane (behind the blocker)
+    z0 = rng.uniform(-0.9, 0.9, n)
+    d = np.stack([np.ones(n), theta, np.zeros(n)], 1)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o = np.stack([np.full(n, -50.0), 0.3 - theta * (50.0 + xh), z0], 1)
+    o, d = (o @ R.T).astype(np.float32), (d @ R.T).astype(np.float32)
+    gpu_ctx.upload_scene(sc)
+    ot, otri, ou, ov, _ = oracle.intersect(sc, o, d)
+    res = {}
+    for cull in (0, 1):
+        gpu_ctx.set_options(cull=cull, traversal=0)
+        res[cull] = gpu_ctx.debug_intersect(o, d)
+    gpu_ctx.set_options(cull=1)
+    t0, tri0, u0, v0 = res[0]
+    assert np.array_equal(tri0, otri) and same(t0, ot) and same(u0, ou) and same(v0, ov)          # cull = 0: exact everywhere
+    t1, tri1, u1, v1 = res[1]
+    differ = (tri1 != otri) | (t1.view(np.uint32) != ot.view(np.uint32))
+    control = theta >= 1e-2
+    assert control.sum() > 10_000 and not differ[control].any()                                   # cull = 1: exact off the grazing band
+    # true distance to the grazed plane, in float64 from the very float32 inputs the kernels saw
+    T = sc.tris[big_ids[0]]
+    p0 = T["v0"].astype(np.float64)
+    N = np.cross(T["v1"].astype(np.float64) - p0, T["v2"].astype(np.float64) - p0)
+    true_t = ((p0 - o.astype(np.float64)) @ N) / (d.astype(np.float64) @ N)
+    for i in np.flatnonzero(differ):
+        assert otri[i] in big_ids                                                                 # the oracle picked a grazing triangle
+        assert abs(ot[i] - true_t[i]) > 1e-3 * abs(true_t[i])                                     # ... at a distance it is not at
+    print(f"grazing rays: {int((~control).sum())}, cull=1 differs from the reference's result on {int(differ.sum())}")

@@ -89,3 +89,21 @@ def test_node_blit_png(tmp_path, oracle):
     ref8 = (np.clip(np.nan_to_num(oracle.blit(hdr), nan=0.0), 0, 1) * 255 + 0.5).astype(np.uint8)
     assert png.shape == (H, W, 4) and (png[..., 3] == 255).all()
     assert (png[..., :3] == ref8[..., :3]).all(axis=-1).mean() >= 0.999
+
+
+@pytest.mark.gpu
+def test_node_blit_rejects_a_buffer_of_the_wrong_size(tmp_path):
+    """addon.blit writes width*height*4 bytes: a short array, or one kept from before resize(), must raise a RangeError
+    in JS instead of reaching the library (which would write past the end of the V8 buffer)."""
+    _build_addon()
+    sc = scenes.make("cornell")
+    scene_io.save_ptscene(sc, str(tmp_path / "c.ptscene"))
+    js = ("var h=require(%r);var r=new h.Renderer({width:16,height:8});r.loadModel(%r).then(function(){"
+          "r.renderFrame();var res=[];var ok=r.blit();res.push(ok.length);"
+          "[new Uint8Array(10),new Uint8Array(16*8*4+4)].forEach(function(b){try{r.addon.blit(r.ctx,b);res.push('no error')}"
+          "catch(e){res.push(e instanceof RangeError?'RangeError':String(e))}});"
+          "r.resize(32,8);try{r.addon.blit(r.ctx,ok);res.push('no error')}catch(e){res.push(e instanceof RangeError?'RangeError':String(e))}"
+          "res.push(r.blit().length);console.log(JSON.stringify(res));r.destroy();})"
+          % (os.path.join(HOST, "renderer.js"), str(tmp_path / "c.ptscene")))
+    out = json.loads(subprocess.check_output([NODE, "-e", js], text=True).strip().splitlines()[-1])
+    assert out == [16 * 8 * 4, "RangeError", "RangeError", "RangeError", 32 * 8 * 4]

@@ -98,6 +98,9 @@ void pt_launch_shadow(hipStream_t s, int blocks, const TraverseConfig &cfg, cons
 void pt_launch_shade(hipStream_t s, int blocks, const DevScene &sc, DevPaths p, const uint32_t *queue,
                      const uint32_t *count, const float4 *hits, DevShadow sh, uint64_t *alive_mask,
                      uint64_t *shadow_mask, ShadeParams sp);
+void pt_launch_shade_fast(hipStream_t s, int blocks, const DevScene &sc, DevPaths p, const uint32_t *queue,
+                          const uint32_t *count, const float4 *hits, DevShadow sh, uint64_t *alive_mask,
+                          uint64_t *shadow_mask, ShadeParams sp);      // perf mode: shade.hip built with fast division / sqrt
 // ordered stream compaction of the survivors: masks -> next queue + its count, plus statistics
 // (tiles = ceil(capacity / pt_compact_tile_slots()) + 1: one workgroup per tile of ballot words)
 uint32_t pt_compact_tile_slots(void);

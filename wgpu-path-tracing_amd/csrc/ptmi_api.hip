@@ -553,9 +553,10 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
                 { Timed t(c, 1, t2); pt_launch_extend(c->stream, blocks, cfg, c->sc, c->paths, q, &c->counts[b], c->hits); }
                 const bool last = b + 1 == maxb;
                 uint64_t *octm = (sort && !last) ? c->octm : nullptr;
-                { Timed t(c, 2, t3); pt_launch_shade(c->stream, blocks, c->sc, c->paths, q, &c->counts[b], c->hits, c->sh,
-                                                     c->alive, c->shadowm,
-                                                     ShadeParams{b, maxb, c->opt.do_mis, c->d_stats, octm, (uint32_t)c->mask_words}); }
+                { Timed t(c, 2, t3);
+                  (c->opt.perf_mode ? pt_launch_shade_fast : pt_launch_shade)(
+                      c->stream, blocks, c->sc, c->paths, q, &c->counts[b], c->hits, c->sh, c->alive, c->shadowm,
+                      ShadeParams{b, maxb, c->opt.do_mis, c->d_stats, octm, (uint32_t)c->mask_words}); }
                 const bool nee = c->opt.do_mis && c->sc.n_lights > 0;
                 { Timed t(c, 5, t3);
                   pt_launch_compact(c->stream, tiles, q, &c->counts[b], c->alive, nee ? c->shadowm : nullptr,

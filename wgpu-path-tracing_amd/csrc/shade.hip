@@ -368,7 +368,15 @@ __global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const
 
 }  // namespace
 
-void pt_launch_shade(hipStream_t s, int blocks, const DevScene &sc, DevPaths p, const uint32_t *queue,
+// This file is built twice (Makefile): once under the arithmetic contract (pt_launch_shade, the default and the only
+// build the parity tests compare with the oracle), once with PT_SHADE_FAST and the compiler's fast division / square root /
+// contraction for ptmi_options.perf_mode = 1 (pt_launch_shade_fast): same source, same RNG draws, same control flow.
+#ifdef PT_SHADE_FAST
+#define PT_LAUNCH_SHADE pt_launch_shade_fast
+#else
+#define PT_LAUNCH_SHADE pt_launch_shade
+#endif
+void PT_LAUNCH_SHADE(hipStream_t s, int blocks, const DevScene &sc, DevPaths p, const uint32_t *queue,
                      const uint32_t *count, const float4 *hits, DevShadow sh, uint64_t *alive_mask,
                      uint64_t *shadow_mask, ShadeParams sp) {
     hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(SBLOCK), 0, s, sc, p, queue, count, hits, sh, alive_mask,

@@ -154,11 +154,12 @@ struct LdsMem {
 // The node test needs no particular arithmetic, only a guarantee: it must pass whenever the contract's slab test passes on
 // the decoded box (which contains the leaf boxes below it, so by monotonicity: whenever a leaf's own test passes). It
 // therefore evaluates the planes' ray distances in one fused step, t~ = fma(k, scale * inv, (origin - o) * inv), and widens
-// the resulting interval by delta, an upper bound of |t~ - t_contract| for every plane of the grid:
+// each axis' interval by delta, an upper bound of |t~ - t_contract| for every plane of the grid on that axis:
 //   t_contract = fl(fl(p - o) * inv) with p = fl(scale * k + origin);  both differ from the real (scale k + origin - o) inv by
 //   rounding errors proportional to |inv| (k scale + |origin| + |o|); adding them up (six roundings, u = 2^-24) gives
-//   |t~ - t_contract| <= 6.1 u |inv| (65535 scale + |origin| + |o|).  delta is that with 16.8 u (1e-6) instead of 6.1 u, the
-//   maximum over the three axes, plus 1e-37 for products that underflow.
+//   |t~ - t_contract| <= 6.1 u |inv| (65535 scale + |origin| + |o|).  delta is that with 16.8 u (1e-6) instead of 6.1 u (room
+//   for the rounding of c -+ delta itself), per axis, plus 1e-37 for products that underflow. In space that is ~1e-6 of the
+//   scene's size: far below one grid step (1.5e-5 of it).
 // Overflow (inf - inf = NaN would void the argument) cannot occur: rays with a component of 1/d beyond 1e18 or an origin
 // beyond 1e15 count as irregular (they walk the uploaded tree with the contract's own test), and a scene that reaches beyond
 // 1e15 is not quantised (fast_tree.hip).
@@ -168,26 +169,33 @@ typedef const __attribute__((address_space(1))) u4v *glb_u4p;
 struct QuantMem {
     glb_u4p qn; glb_u32p ls; glb_f4p tp;
     float ox, oy, oz, sx, sy, sz;
-    struct RayK { float kx, ky, kz, cx, cy, cz, delta; };
+    struct RayK { float kx, ky, kz, nx, ny, nz, fx, fy, fz; };    // t~ of plane number q: near side fma(q, k, n), far side fma(q, k, f)
     PT_DEV static bool in_range(v3 o, v3 inv) {
         return (__builtin_fabsf(inv.x) <= 1e18f) & (__builtin_fabsf(inv.y) <= 1e18f) & (__builtin_fabsf(inv.z) <= 1e18f) &
                (__builtin_fabsf(o.x) <= 1e15f) & (__builtin_fabsf(o.y) <= 1e15f) & (__builtin_fabsf(o.z) <= 1e15f);
     }
     PT_DEV void prep(v3 o, v3 inv, RayK &r) const {
         r.kx = sx * inv.x; r.ky = sy * inv.y; r.kz = sz * inv.z;
-        r.cx = (ox - o.x) * inv.x; r.cy = (oy - o.y) * inv.y; r.cz = (oz - o.z) * inv.z;
-        const float dx = __builtin_fabsf(inv.x) * (65535.0f * sx + __builtin_fabsf(ox) + __builtin_fabsf(o.x));
-        const float dy = __builtin_fabsf(inv.y) * (65535.0f * sy + __builtin_fabsf(oy) + __builtin_fabsf(o.y));
-        const float dz = __builtin_fabsf(inv.z) * (65535.0f * sz + __builtin_fabsf(oz) + __builtin_fabsf(o.z));
-        r.delta = max1(max1(dx, dy), dz) * 1e-6f + 1e-37f;
+        const float cx = (ox - o.x) * inv.x, cy = (oy - o.y) * inv.y, cz = (oz - o.z) * inv.z;
+        const float dx = __builtin_fabsf(inv.x) * (65535.0f * sx + __builtin_fabsf(ox) + __builtin_fabsf(o.x)) * 1e-6f + 1e-37f;
+        const float dy = __builtin_fabsf(inv.y) * (65535.0f * sy + __builtin_fabsf(oy) + __builtin_fabsf(o.y)) * 1e-6f + 1e-37f;
+        const float dz = __builtin_fabsf(inv.z) * (65535.0f * sz + __builtin_fabsf(oz) + __builtin_fabsf(o.z)) * 1e-6f + 1e-37f;
+        r.nx = cx - dx; r.ny = cy - dy; r.nz = cz - dz;
+        r.fx = cx + dx; r.fy = cy + dy; r.fz = cz + dz;
     }
     PT_DEV static bool qslab(uint32_t w0, uint32_t w1, uint32_t w2, const RayK &r, float &tmin) {
-        // words: lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16
-        const float t1x = fma1((float)(w0 & 0xFFFFu), r.kx, r.cx), t2x = fma1((float)(w1 >> 16), r.kx, r.cx);
-        const float t1y = fma1((float)(w0 >> 16), r.ky, r.cy), t2y = fma1((float)(w2 & 0xFFFFu), r.ky, r.cy);
-        const float t1z = fma1((float)(w1 & 0xFFFFu), r.kz, r.cz), t2z = fma1((float)(w2 >> 16), r.kz, r.cz);
-        tmin = max1(max1(min1(t1x, t2x), min1(t1y, t2y)), min1(t1z, t2z)) - r.delta;
-        const float tmax = min1(min1(max1(t1x, t2x), max1(t1y, t2y)), max1(t1z, t2z)) + r.delta;
+        // words: lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16. scale >= 0, so k has the sign of 1/d: the plane the ray
+        // meets first is the low one when k >= 0 and the high one otherwise — no min / max per axis, and each side of the
+        // interval is widened by its own axis' delta (folded into n and f)
+        const float lx = (float)(w0 & 0xFFFFu), hx = (float)(w1 >> 16);
+        const float ly = (float)(w0 >> 16), hy = (float)(w2 & 0xFFFFu);
+        const float lz = (float)(w1 & 0xFFFFu), hz = (float)(w2 >> 16);
+        const bool px = r.kx >= 0.0f, py = r.ky >= 0.0f, pz = r.kz >= 0.0f;
+        const float nx = fma1(px ? lx : hx, r.kx, r.nx), fx = fma1(px ? hx : lx, r.kx, r.fx);
+        const float ny = fma1(py ? ly : hy, r.ky, r.ny), fy = fma1(py ? hy : ly, r.ky, r.fy);
+        const float nz = fma1(pz ? lz : hz, r.kz, r.nz), fz = fma1(pz ? hz : lz, r.kz, r.fz);
+        tmin = max1(max1(nx, ny), nz);
+        const float tmax = min1(min1(fx, fy), fz);
         return tmax >= tmin && tmax >= 0.0f;
     }
     PT_DEV void test(uint32_t i, v3, v3, const RayK &r, bool &hl, bool &hr, float &tl, float &tr, uint32_t &lref, uint32_t &rref) const {
