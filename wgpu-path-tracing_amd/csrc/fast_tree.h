@@ -23,4 +23,7 @@ void pt_build_fast_tree(const std::vector<PtFastLeaf> &leaves, std::vector<float
 // tripos: 3 float4 per triangle (v0, e1, e2), indexed by triangle. Returns false when the hierarchy cannot be quantised
 // (non-finite boxes, a stream beyond 2^31 dwords); the caller then keeps the exact image.
 bool pt_quantize_tree(const std::vector<PtFastLeaf> &leaves, const std::vector<float4> &wnodes, const std::vector<float4> &tripos,
-                      std::vector<uint4> &qnodes, std::vector<uint32_t> &stream, float origin[3], float scale[3]);
+                      std::vector<uint4> &qnodes, std::vector<uint32_t> &stream, float origin[3], float scale[3],
+                      uint32_t top_nodes, uint32_t &n_top);
+// The quantised nodes are renumbered: the first n_top (<= top_nodes) are the top of the tree in breadth-first order (the
+// kernel keeps them in LDS), the others follow in their preorder. The root stays node 0.

@@ -180,8 +180,9 @@ void pt_build_fast_tree(const std::vector<PtFastLeaf> &leaves, std::vector<float
 
 // ---- quantised image ------------------------------------------------------------------------------------------------
 bool pt_quantize_tree(const std::vector<PtFastLeaf> &leaves, const std::vector<float4> &wnodes, const std::vector<float4> &tripos,
-                      std::vector<uint4> &qnodes, std::vector<uint32_t> &stream, float origin[3], float scale[3]) {
-    qnodes.clear(); stream.clear();
+                      std::vector<uint4> &qnodes, std::vector<uint32_t> &stream, float origin[3], float scale[3],
+                      uint32_t top_nodes, uint32_t &n_top) {
+    qnodes.clear(); stream.clear(); n_top = 0;
     const size_t n_nodes = wnodes.size() / 4;
     if (n_nodes == 0 || leaves.empty()) return false;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -189,7 +190,6 @@ bool pt_quantize_tree(const std::vector<PtFastLeaf> &leaves, const std::vector<f
     for (const PtFastLeaf &l : leaves) {
         for (int k = 0; k < 3; k++) {
             if (!std::isfinite(l.mn[k]) || !std::isfinite(l.mx[k]) || l.mn[k] > l.mx[k]) return false;
-            if (std::fabs(l.mn[k]) > 1e15f || std::fabs(l.mx[k]) > 1e15f) return false;       // the node test's error bound assumes no overflow (traverse.hip)
             mn[k] = std::min(mn[k], l.mn[k]); mx[k] = std::max(mx[k], l.mx[k]);
         }
         n_tri_refs += l.weight;
@@ -244,6 +244,21 @@ bool pt_quantize_tree(const std::vector<PtFastLeaf> &leaves, const std::vector<f
     if (total >= (1ull << 31)) return false;
     stream.assign(total, 0u);
     qnodes.resize(n_nodes * 2);
+    // new numbers: the top of the tree breadth-first (root first), then everything else in preorder
+    std::vector<uint32_t> renum(n_nodes, 0xFFFFFFFFu);
+    {
+        std::vector<uint32_t> bfs; bfs.reserve(top_nodes);
+        bfs.push_back(0u);
+        for (size_t h = 0; h < bfs.size() && bfs.size() < top_nodes; h++) {
+            uint32_t refs[2]; std::memcpy(&refs[0], &wnodes[(size_t)bfs[h] * 4 + 3].x, 4); std::memcpy(&refs[1], &wnodes[(size_t)bfs[h] * 4 + 3].y, 4);
+            for (int c = 0; c < 2 && bfs.size() < top_nodes; c++)
+                if (!(refs[c] & PT_REF_LEAF)) bfs.push_back(refs[c]);
+        }
+        for (size_t k = 0; k < bfs.size(); k++) renum[bfs[k]] = (uint32_t)k;
+        n_top = (uint32_t)bfs.size();
+        uint32_t next = n_top;
+        for (size_t i = 0; i < n_nodes; i++) if (renum[i] == 0xFFFFFFFFu) renum[i] = next++;
+    }
     auto area = [](const float *l, const float *h) {
         const double x = (double)h[0] - l[0], y = (double)h[1] - l[1], z = (double)h[2] - l[2];
         return 2.0 * (x * y + y * z + z * x);
@@ -268,8 +283,10 @@ bool pt_quantize_tree(const std::vector<PtFastLeaf> &leaves, const std::vector<f
                     for (uint32_t t = 0; t < cnt; t++)
                         for (int j = 0; j < 3; j++) std::memcpy(h + 8 + 9 * t + 3 * j, &tripos[3 * (size_t)(first + t) + j], 12);
                     ref = PT_REF_LEAF | child_off[i * 2 + c];
+                } else {
+                    ref = renum[ref];
                 }
-                qnodes[i * 2 + c] = make_uint4(ql[0] | (ql[1] << 16), ql[2] | (qh[0] << 16), qh[1] | (qh[2] << 16), ref);
+                qnodes[(size_t)renum[i] * 2 + c] = make_uint4(ql[0] | (ql[1] << 16), ql[2] | (qh[0] << 16), qh[1] | (qh[2] << 16), ref);
                 float dl[3], dh[3];
                 for (int k = 0; k < 3; k++) { dl[k] = std::fmaf(scale[k], (float)ql[k], origin[k]); dh[k] = std::fmaf(scale[k], (float)qh[k], origin[k]); }
                 const double a0 = area(lo[c], hi[c]);

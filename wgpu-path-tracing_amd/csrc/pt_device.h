@@ -41,6 +41,7 @@ struct DevScene {
     // (per leaf: exact box + first triangle + count, then 9 dwords per triangle).
     const uint4 *qnodes;        const uint32_t *leaf_stream;
     float q_origin[3], q_scale[3];
+    uint32_t q_cached;          // the first q_cached quantised nodes are the top levels in breadth-first order (kept in LDS)
 };
 
 // ---- path state: 64 B per path, four float4 streams indexed by path id ----
@@ -82,6 +83,9 @@ struct TraverseConfig {
     uint32_t *spill;        // global variant: per-lane overflow of the node stack, pt_spill_bytes(blocks) bytes
     int quantized;          // global variant: walk the quantised image when the scene has one
 };
+#ifndef PT_QCACHE_NODES
+#define PT_QCACHE_NODES 256      /* quantised nodes of the top levels staged in LDS per workgroup (8 KB) */
+#endif
 #define PT_SPILL_ENTRIES 64     /* >= the deepest node stack: upload rejects trees deeper than 62 */
 size_t pt_spill_bytes(int blocks);
 

@@ -175,6 +175,7 @@ struct Built {
     double tree_ms = 0.0;                    // time spent in pt_build_fast_tree
     std::vector<uint4> qnodes; std::vector<uint32_t> leaf_stream;     // quantised image (empty: none)
     float q_origin[3] = {0, 0, 0}, q_scale[3] = {0, 0, 0};
+    uint32_t q_top = 0;                      // quantised nodes numbered breadth-first at the front (LDS-resident in the kernel)
 };
 
 uint32_t leaf_ref(const ptmi_bvh_node &n) {
@@ -273,7 +274,8 @@ int build_image(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_
     }
     {
         const auto t0 = std::chrono::steady_clock::now();
-        if (!b.fast_wnodes.empty() && !pt_quantize_tree(leaves, b.fast_wnodes, b.tripos, b.qnodes, b.leaf_stream, b.q_origin, b.q_scale)) {
+        if (!b.fast_wnodes.empty() && !pt_quantize_tree(leaves, b.fast_wnodes, b.tripos, b.qnodes, b.leaf_stream, b.q_origin, b.q_scale,
+                                                         PT_QCACHE_NODES, b.q_top)) {
             b.qnodes.clear(); b.leaf_stream.clear();
         }
         b.tree_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -448,6 +450,7 @@ int ptmi_upload_scene(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const
     s.tripos = c->d_tripos;
     s.qnodes = c->d_qnodes; s.leaf_stream = c->d_leaf_stream;
     for (int k = 0; k < 3; k++) { s.q_origin[k] = b.q_origin[k]; s.q_scale[k] = b.q_scale[k]; }
+    s.q_cached = b.q_top;
     for (int k = 0; k < 3; k++) { s.root_min[k] = b.root_min[k]; s.root_max[k] = b.root_max[k]; }
     s.root_ref = fast ? b.fast_root : b.root_ref;
     c->bvh_depth = std::max(b.depth, b.fast_depth);           // stacks must hold either tree (irregular rays use the uploaded one)
@@ -770,13 +773,21 @@ int ptmi_debug_image_stats(const ptmi_triangle *tris, uint32_t nt, const ptmi_bv
         double x = (double)hi[0] - lo[0], y = (double)hi[1] - lo[1], z = (double)hi[2] - lo[2];
         return 2.0 * (x * y + y * z + z * x);
     };
-    for (size_t i = 0; i < b.qnodes.size() / 2; i++) {
-        const float4 *w = &b.fast_wnodes[i * 4];
+    // the quantised nodes are renumbered (top levels first): walk both images together from their roots
+    std::vector<std::pair<uint32_t, uint32_t>> todo;       // (node of the exact image, node of the quantised image)
+    todo.push_back({0u, 0u});
+    size_t visited = 0;
+    while (!todo.empty()) {
+        const uint32_t i = todo.back().first, qi = todo.back().second;
+        todo.pop_back();
+        if ((size_t)qi * 2 + 1 >= b.qnodes.size() || (size_t)i * 4 + 3 >= b.fast_wnodes.size()) { bad_hdr++; continue; }
+        visited++;
+        const float4 *w = &b.fast_wnodes[(size_t)i * 4];
         const float lo[2][3] = {{w[0].x, w[0].y, w[0].z}, {w[1].z, w[1].w, w[2].x}};
         const float hi[2][3] = {{w[0].w, w[1].x, w[1].y}, {w[2].y, w[2].z, w[2].w}};
         uint32_t refs[2]; std::memcpy(&refs[0], &w[3].x, 4); std::memcpy(&refs[1], &w[3].y, 4);
         for (int ch = 0; ch < 2; ch++) {
-            const uint4 q = b.qnodes[i * 2 + ch];
+            const uint4 q = b.qnodes[(size_t)qi * 2 + ch];
             const uint32_t pl[6] = {q.x & 0xFFFFu, q.x >> 16, q.y & 0xFFFFu, q.y >> 16, q.z & 0xFFFFu, q.z >> 16};   // lo.xyz, hi.xyz
             float dlo[3], dhi[3];
             for (int k = 0; k < 3; k++) {
@@ -801,9 +812,11 @@ int ptmi_debug_image_stats(const ptmi_triangle *tris, uint32_t nt, const ptmi_bv
                         ok = ok && std::memcmp(&g[0], &v.x, 4) == 0 && std::memcmp(&g[1], &v.y, 4) == 0 && std::memcmp(&g[2], &v.z, 4) == 0;
                     }
                 if (!ok) bad_hdr++;
-            } else if (q.w != refs[ch]) bad_hdr++;
+            } else if (q.w & PT_REF_LEAF) bad_hdr++;
+            else todo.push_back({refs[ch], q.w});
         }
     }
+    if (visited != b.qnodes.size() / 2) bad_hdr++;          // every node reached exactly once (a tree: no node can be reached twice)
     out[1] = (double)leaves; out[5] = viol; out[6] = boxes ? infl / (double)boxes : 0.0; out[7] = (double)bad_hdr;
     return PTMI_OK;
 }

@@ -151,61 +151,32 @@ struct LdsMem {
 // Half the bytes per node step and 25 % fewer per triangle: this variant waits on L2 / Infinity Cache as much as on the ALUs.
 // Lanes that walk the tree as uploaded (`old`) read the exact 64-B image and the 48-B triangle images instead.
 //
-// The node test needs no particular arithmetic, only a guarantee: it must pass whenever the contract's slab test passes on
-// the decoded box (which contains the leaf boxes below it, so by monotonicity: whenever a leaf's own test passes). It
-// therefore evaluates the planes' ray distances in one fused step, t~ = fma(k, scale * inv, (origin - o) * inv), and widens
-// each axis' interval by delta, an upper bound of |t~ - t_contract| for every plane of the grid on that axis:
-//   t_contract = fl(fl(p - o) * inv) with p = fl(scale * k + origin);  both differ from the real (scale k + origin - o) inv by
-//   rounding errors proportional to |inv| (k scale + |origin| + |o|); adding them up (six roundings, u = 2^-24) gives
-//   |t~ - t_contract| <= 6.1 u |inv| (65535 scale + |origin| + |o|).  delta is that with 16.8 u (1e-6) instead of 6.1 u (room
-//   for the rounding of c -+ delta itself), per axis, plus 1e-37 for products that underflow. In space that is ~1e-6 of the
-//   scene's size: far below one grid step (1.5e-5 of it).
-// Overflow (inf - inf = NaN would void the argument) cannot occur: rays with a component of 1/d beyond 1e18 or an origin
-// beyond 1e15 count as irregular (they walk the uploaded tree with the contract's own test), and a scene that reaches beyond
-// 1e15 is not quantised (fast_tree.hip).
+// The decoded planes go through the contract's own slab arithmetic. (Tried: one fused step per plane,
+// fma(k, scale * inv, (origin - o) * inv), with each axis' interval widened by a proven bound of its rounding error — any
+// test that passes whenever the contract's passes would do for inner boxes. 24 VALU instructions fewer per node, 9 more
+// registers per ray: 5 waves per SIMD instead of 6, extend -3 %, shadow +11 % on the 1 M-triangle scene. The kernel waits on
+// node fetches as much as on the ALUs; registers are worth more than instructions here.)
 typedef const __attribute__((address_space(1))) uint32_t *glb_u32p;
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) u4v *glb_u4p;
+typedef const __attribute__((address_space(3))) u4v *lds_u4p;
 struct QuantMem {
     glb_u4p qn; glb_u32p ls; glb_f4p tp;
     float ox, oy, oz, sx, sy, sz;
-    struct RayK { float kx, ky, kz, nx, ny, nz, fx, fy, fz; };    // t~ of plane number q: near side fma(q, k, n), far side fma(q, k, f)
-    PT_DEV static bool in_range(v3 o, v3 inv) {
-        return (__builtin_fabsf(inv.x) <= 1e18f) & (__builtin_fabsf(inv.y) <= 1e18f) & (__builtin_fabsf(inv.z) <= 1e18f) &
-               (__builtin_fabsf(o.x) <= 1e15f) & (__builtin_fabsf(o.y) <= 1e15f) & (__builtin_fabsf(o.z) <= 1e15f);
-    }
-    PT_DEV void prep(v3 o, v3 inv, RayK &r) const {
-        r.kx = sx * inv.x; r.ky = sy * inv.y; r.kz = sz * inv.z;
-        const float cx = (ox - o.x) * inv.x, cy = (oy - o.y) * inv.y, cz = (oz - o.z) * inv.z;
-        const float dx = __builtin_fabsf(inv.x) * (65535.0f * sx + __builtin_fabsf(ox) + __builtin_fabsf(o.x)) * 1e-6f + 1e-37f;
-        const float dy = __builtin_fabsf(inv.y) * (65535.0f * sy + __builtin_fabsf(oy) + __builtin_fabsf(o.y)) * 1e-6f + 1e-37f;
-        const float dz = __builtin_fabsf(inv.z) * (65535.0f * sz + __builtin_fabsf(oz) + __builtin_fabsf(o.z)) * 1e-6f + 1e-37f;
-        r.nx = cx - dx; r.ny = cy - dy; r.nz = cz - dz;
-        r.fx = cx + dx; r.fy = cy + dy; r.fz = cz + dz;
-    }
-    PT_DEV static bool qslab(uint32_t w0, uint32_t w1, uint32_t w2, const RayK &r, float &tmin) {
-        // words: lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16. scale >= 0, so k has the sign of 1/d: the plane the ray
-        // meets first is the low one when k >= 0 and the high one otherwise — no min / max per axis, and each side of the
-        // interval is widened by its own axis' delta (folded into n and f)
-        const float lx = (float)(w0 & 0xFFFFu), hx = (float)(w1 >> 16);
-        const float ly = (float)(w0 >> 16), hy = (float)(w2 & 0xFFFFu);
-        const float lz = (float)(w1 & 0xFFFFu), hz = (float)(w2 >> 16);
-        const bool px = r.kx >= 0.0f, py = r.ky >= 0.0f, pz = r.kz >= 0.0f;
-        const float nx = fma1(px ? lx : hx, r.kx, r.nx), fx = fma1(px ? hx : lx, r.kx, r.fx);
-        const float ny = fma1(py ? ly : hy, r.ky, r.ny), fy = fma1(py ? hy : ly, r.ky, r.fy);
-        const float nz = fma1(pz ? lz : hz, r.kz, r.nz), fz = fma1(pz ? hz : lz, r.kz, r.fz);
-        tmin = max1(max1(nx, ny), nz);
-        const float tmax = min1(min1(fx, fy), fz);
-        return tmax >= tmin && tmax >= 0.0f;
-    }
-    PT_DEV void test(uint32_t i, v3, v3, const RayK &r, bool &hl, bool &hr, float &tl, float &tr, uint32_t &lref, uint32_t &rref) const {
-        const u4v l = qn[2u * (size_t)i], rr = qn[2u * (size_t)i + 1u];
-        hl = qslab(l.x, l.y, l.z, r, tl);
-        hr = qslab(rr.x, rr.y, rr.z, r, tr);
-        lref = l.w; rref = rr.w;
+    lds_u4p qc; uint32_t n_cached;        // the first n_cached nodes (the top levels, numbered breadth-first) also live in LDS
+    struct RayK {};
+    PT_DEV static bool in_range(v3, v3) { return true; }
+    PT_DEV void prep(v3, v3, RayK &) const {}
+    PT_DEV void test(uint32_t i, v3 o, v3 inv, const RayK &, bool &hl, bool &hr, float &tl, float &tr, uint32_t &lref, uint32_t &rref) const {
+        Boxes nb; node(i, false, nb);
+        hl = slab(nb.lx0, nb.ly0, nb.lz0, nb.lx1, nb.ly1, nb.lz1, o, inv, tl);
+        hr = slab(nb.rx0, nb.ry0, nb.rz0, nb.rx1, nb.ry1, nb.rz1, o, inv, tr);
+        lref = nb.lref; rref = nb.rref;
     }
     PT_DEV void node(uint32_t i, bool, Boxes &b) const {
-        const u4v l = qn[2u * (size_t)i], r = qn[2u * (size_t)i + 1u];
+        u4v l, r;
+        if (i < n_cached) { l = qc[2u * i]; r = qc[2u * i + 1u]; }
+        else { l = qn[2u * (size_t)i]; r = qn[2u * (size_t)i + 1u]; }
         b.lx0 = fma1(sx, (float)(l.x & 0xFFFFu), ox); b.ly0 = fma1(sy, (float)(l.x >> 16), oy);
         b.lz0 = fma1(sz, (float)(l.y & 0xFFFFu), oz); b.lx1 = fma1(sx, (float)(l.y >> 16), ox);
         b.ly1 = fma1(sy, (float)(l.z & 0xFFFFu), oy); b.lz1 = fma1(sz, (float)(l.z >> 16), oz);
@@ -514,8 +485,14 @@ __global__ __launch_bounds__(GBLOCK) PT_GLOBAL_ATTR void k_trace_global(DevScene
     if (gw * 64u >= count) return;
     uint32_t *sp = spill + (size_t)blockIdx.x * GBLOCK + threadIdx.x;
     if constexpr (QUANT) {
+        // the top of the tree (every ray's first steps) is read from LDS: the upload numbers those nodes breadth-first
+        __shared__ uint4 qcache[2 * PT_QCACHE_NODES];
+        const uint32_t nc = sc.q_cached < PT_QCACHE_NODES ? sc.q_cached : PT_QCACHE_NODES;
+        for (uint32_t i = threadIdx.x; i < 2u * nc; i += GBLOCK) qcache[i] = sc.qnodes[i];
+        __syncthreads();
         QuantMem m{(glb_u4p)sc.qnodes, (glb_u32p)sc.leaf_stream, (glb_f4p)sc.tripos,
-                   sc.q_origin[0], sc.q_origin[1], sc.q_origin[2], sc.q_scale[0], sc.q_scale[1], sc.q_scale[2]};
+                   sc.q_origin[0], sc.q_origin[1], sc.q_origin[2], sc.q_scale[0], sc.q_scale[1], sc.q_scale[2],
+                   (lds_u4p)qcache, nc};
         trace_wave<MODE, CULL, STACK, true>(m, sc, io, count, gw, gridDim.x * (GBLOCK / 64), stk + threadIdx.x, GBLOCK, sp, gridDim.x * GBLOCK);
     } else {
         GlobalMem m{(glb_f4p)sc.wnodes, (glb_f4p)sc.tripos};
