@@ -13,4 +13,5 @@ run cfg3_exact_$i --config 3 --traversal global_exact || exit 1
 done
 run cfg3_sort --config 3 --sort 1 &&
 run cfg1_parity --config 1 && run cfg1_perf --config 1 --perf-mode 1 && run cfg1_parity2 --config 1 && run cfg1_perf2 --config 1 --perf-mode 1 &&
-run cfg2_perf --config 2 --steps 4 --perf-mode 1 && run cfg2_parity --config 2 --steps 4
+run cfg2_perf --config 2 --steps 4 --perf-mode 1 && run cfg2_parity --config 2 --steps 4 &&
+bash tools/pmc_cfg.sh 3 cfg3 > $out/pmc_cfg3.log 2>&1; cat $out/pmc_cfg3.log
