@@ -482,19 +482,22 @@ __global__ __launch_bounds__(GBLOCK) PT_GLOBAL_ATTR void k_trace_global(DevScene
     __shared__ uint32_t stk[STACK * GBLOCK];
     const uint32_t count = *count_ptr;
     const uint32_t gw = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;       // consecutive groups -> different workgroups
-    if (gw * 64u >= count) return;
     uint32_t *sp = spill + (size_t)blockIdx.x * GBLOCK + threadIdx.x;
     if constexpr (QUANT) {
-        // the top of the tree (every ray's first steps) is read from LDS: the upload numbers those nodes breadth-first
+        // the top of the tree (every ray's first steps) is read from LDS: the upload numbers those nodes breadth-first.
+        // Filled by ALL 256 threads, before any wave may leave (a wave without rays would otherwise leave its share unfilled)
         __shared__ uint4 qcache[2 * PT_QCACHE_NODES];
         const uint32_t nc = sc.q_cached < PT_QCACHE_NODES ? sc.q_cached : PT_QCACHE_NODES;
+        if (blockIdx.x * 64u >= count) return;                               // wave 0 owns the lowest group: the whole workgroup is idle
         for (uint32_t i = threadIdx.x; i < 2u * nc; i += GBLOCK) qcache[i] = sc.qnodes[i];
         __syncthreads();
+        if (gw * 64u >= count) return;
         QuantMem m{(glb_u4p)sc.qnodes, (glb_u32p)sc.leaf_stream, (glb_f4p)sc.tripos,
                    sc.q_origin[0], sc.q_origin[1], sc.q_origin[2], sc.q_scale[0], sc.q_scale[1], sc.q_scale[2],
                    (lds_u4p)qcache, nc};
         trace_wave<MODE, CULL, STACK, true>(m, sc, io, count, gw, gridDim.x * (GBLOCK / 64), stk + threadIdx.x, GBLOCK, sp, gridDim.x * GBLOCK);
     } else {
+        if (gw * 64u >= count) return;
         GlobalMem m{(glb_f4p)sc.wnodes, (glb_f4p)sc.tripos};
         trace_wave<MODE, CULL, STACK, true>(m, sc, io, count, gw, gridDim.x * (GBLOCK / 64), stk + threadIdx.x, GBLOCK, sp, gridDim.x * GBLOCK);
     }
