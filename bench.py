@@ -25,7 +25,7 @@ ONE RCCL gather, inside the timed region. value = all ranks' path segments / max
 Rank r renders the strips r, r + N, ... (4 rows each, fewer when the frame height is not a whole number of such rounds: 3 for 2160 rows over 8 ranks).
 
 Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel (closest-hit traversal `extend`) against HBM:
-algorithmic bytes per ray = 32 (origin+direction float4 pair) + 4 (queue index) + 16 (hit record) = 52 B (DESIGN.md
+algorithmic bytes per ray = 32 (origin+direction float4 pair) + 4 (queue index) + 8 (hit record) = 44 B (DESIGN.md
 §5), launch durations from HIP events recorded by the library on its own stream around every launch
 (`--timing 3`: every kernel, so `kernel_ms_rank0` adds up to `gpu_ms_rank0`); `roofline.kernels` carries the same
 figures for shade and shadow. `roofline.traffic` replays the committed rocprofv3 counter passes of the same command
@@ -44,7 +44,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "wgpu-path-tracing_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-EXTEND_BYTES_PER_RAY = 32 + 4 + 16      # queue 4 + O,D 32 read, hit 16 written
+EXTEND_BYTES_PER_RAY = 32 + 4 + 8       # queue 4 + O,D 32 read, hit record (t, triangle) 8 written
 SHADOW_BYTES_PER_RAY = 4 + 48 + 32      # index 4 + record 48 read, radiance RMW 32 (unoccluded)
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
 PROFILE_TAG = "r02"                     # profiles/<tag>_cfgN_*.json are the counter passes replayed in `roofline`
@@ -64,21 +64,21 @@ CONFIGS = {
 
 
 def shade_bytes_per_segment(do_mis, p_record, bounce0_share):
-    """queue 4 + hit 16 + O,D,T 48 read, O,D,T 48 written (survivors; priced for every segment), ballots 1/4,
-    + 48 per emitted shadow record; bounce 0 reads neither a queue nor a stored throughput."""
-    b = 4 + 16 + 48 + 48 + 0.25 + (48 * p_record if do_mis else 0.0)
-    return b - bounce0_share * (4 + 16)
+    """queue 4 + hit 8 + O,D,C 40 read, O,D,C 40 written (survivors; priced for every segment), ballots 1/4,
+    + 48 per emitted shadow record; bounce 0 reads neither a queue nor a stored throughput (C)."""
+    b = 4 + 8 + 40 + 40 + 0.25 + (48 * p_record if do_mis else 0.0)
+    return b - bounce0_share * (4 + 8)
 
 
 def pipeline_bytes_per_segment(do_mis, mean_len):
     """SURVEY.md §8(d) re-derived for this build's records:
-    extend R 32+4 W 16; shade R 4+16+48 (O,D,T) W 48 + masks 0.25; compact R 4 W 4;
+    extend R 32+4 W 8; shade R 4+8+40 (O,D,C) W 40 + masks 0.25; compact R 4 W 4;
     MIS: shadow record W 48 R 48 + radiance RMW 32; per path: raygen W 48 (O, D, L), accumulate R 16 + frame RMW 32,
-    less what bounce 0 does not touch (the identity queue, 3 x 4, and the stored throughput, 16)."""
-    seg = (32 + 4 + 16) + (4 + 16 + 48 + 48) + 8
+    less what bounce 0 does not touch (the identity queue, 3 x 4, and the stored part of the throughput, 8)."""
+    seg = (32 + 4 + 8) + (4 + 8 + 40 + 40) + 8
     if do_mis:
         seg += 48 + 48 + 32
-    return seg + (48 + 48 - 12 - 16) / max(mean_len, 1e-9)
+    return seg + (48 + 48 - 12 - 8) / max(mean_len, 1e-9)
 
 
 def _git_commit_of(path):

@@ -16,17 +16,17 @@ def _bench():
 
 def test_byte_model_matches_design():
     b = _bench()
-    assert b.EXTEND_BYTES_PER_RAY == 4 + 32 + 16
-    # 52 + 116 + 8 (+128 with MIS) + (48 + 48 - 28) / mean path length
-    assert abs(b.pipeline_bytes_per_segment(1, 2.0) - (304 + 34)) < 1e-9
-    assert abs(b.pipeline_bytes_per_segment(0, 4.0) - (176 + 17)) < 1e-9
+    assert b.EXTEND_BYTES_PER_RAY == 4 + 32 + 8
+    # 44 + 92 + 8 (+128 with MIS) + (48 + 48 - 20) / mean path length
+    assert abs(b.pipeline_bytes_per_segment(1, 2.0) - (272 + 38)) < 1e-9
+    assert abs(b.pipeline_bytes_per_segment(0, 4.0) - (144 + 19)) < 1e-9
 
 
 def test_shade_byte_model():
     b = _bench()
-    # queue 4 + hit 16 + O,D,T 48 read, 48 written, ballots 1/4, + 48 per emitted shadow record
-    assert abs(b.shade_bytes_per_segment(1, 0.5, 0.0) - (116.25 + 24)) < 1e-9
-    assert abs(b.shade_bytes_per_segment(0, 0.5, 1.0) - (116.25 - 20)) < 1e-9      # bounce 0 reads no queue, no throughput
+    # queue 4 + hit 8 + O,D,C 40 read, 40 written, ballots 1/4, + 48 per emitted shadow record
+    assert abs(b.shade_bytes_per_segment(1, 0.5, 0.0) - (92.25 + 24)) < 1e-9
+    assert abs(b.shade_bytes_per_segment(0, 0.5, 1.0) - (92.25 - 12)) < 1e-9       # bounce 0 reads no queue, no stored throughput
 
 
 def test_configs_are_baseline_json():

@@ -38,7 +38,7 @@ PT_DEV void camera_ray(const ptmi_camera &cam, uint32_t x, uint32_t y, uint32_t 
     }
 }
 
-// The throughput of pt.wgsl:639 is not stored: `shade` knows it is (1, 1, 1) at bounce 0 and writes T from then on.
+// The throughput of pt.wgsl:639 is not stored: `shade` knows it is (1, 1, 1) at bounce 0 and writes D.w / C from then on.
 PT_DEV void init_path(DevPaths P, uint32_t p, v3 o, v3 d, uint32_t rng) {
     P.O[p] = make_float4(o.x, o.y, o.z, __uint_as_float(rng));
     P.D[p] = make_float4(d.x, d.y, d.z, 0.0f);

@@ -44,11 +44,11 @@ struct DevScene {
     uint32_t q_cached;          // the first q_cached quantised nodes are the top levels in breadth-first order (kept in LDS)
 };
 
-// ---- path state: 64 B per path, four float4 streams indexed by path id ----
-//   O = (origin.xyz, bits(rng state))   D = (direction.xyz, 0)
-//   T = (throughput.xyz, 0)             L = (radiance.xyz, 0)
-struct DevPaths { float4 *O, *D, *T, *L; };
-// hit record, 16 B per queue slot: (t, u, v, bits(triangle index)); t = -1 on a miss
+// ---- path state: 56 B per path, four streams indexed by path id ----
+//   O = (origin.xyz, bits(rng state))   D = (direction.xyz, throughput.x)      the two float4 `extend` reads
+//   C = (throughput.y, throughput.z)    L = (radiance.xyz, 0)
+struct DevPaths { float4 *O, *D; float2 *C; float4 *L; };
+// hit record, 8 B per queue slot: (t, bits(triangle index)); t = -1 on a miss. `shade` rebuilds (u, v) from the triangle.
 // shadow record, 48 B per queue slot:
 //   SO = (origin.xyz, dist or -1 for directional)  SD = (wi.xyz, bits(path id))
 //   SC = (throughput * directLight .xyz, 0)   added to L[path] when unoccluded
@@ -95,15 +95,17 @@ void pt_launch_raygen(hipStream_t s, int blocks, const ptmi_camera &cam, DevBand
 void pt_launch_raygen_list(hipStream_t s, const ptmi_camera &cam, uint32_t n, const uint32_t *xs,
                            const uint32_t *ys, const uint32_t *frames, DevPaths p);
 void pt_launch_extend(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, DevPaths p,
-                      const uint32_t *queue, const uint32_t *count, float4 *hits);
+                      const uint32_t *queue, const uint32_t *count, float2 *hits);
+// (u, v) of n hit records, rebuilt the way `shade` does it (debug entry point of the parity tests)
+void pt_launch_hit_uv(hipStream_t s, uint32_t n, const DevScene &sc, DevPaths p, const float2 *hits, float2 *uv);
 // shadow_queue: slots of the shadow records to trace (NULL = slots 0..count-1), count = their number
 void pt_launch_shadow(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, DevPaths p,
                       DevShadow sh, const uint32_t *shadow_queue, const uint32_t *count, uint8_t *occluded_out);
 void pt_launch_shade(hipStream_t s, int blocks, const DevScene &sc, DevPaths p, const uint32_t *queue,
-                     const uint32_t *count, const float4 *hits, DevShadow sh, uint64_t *alive_mask,
+                     const uint32_t *count, const float2 *hits, DevShadow sh, uint64_t *alive_mask,
                      uint64_t *shadow_mask, ShadeParams sp);
 void pt_launch_shade_fast(hipStream_t s, int blocks, const DevScene &sc, DevPaths p, const uint32_t *queue,
-                          const uint32_t *count, const float4 *hits, DevShadow sh, uint64_t *alive_mask,
+                          const uint32_t *count, const float2 *hits, DevShadow sh, uint64_t *alive_mask,
                           uint64_t *shadow_mask, ShadeParams sp);      // perf mode: shade.hip built with fast division / sqrt
 // ordered stream compaction of the survivors: masks -> next queue + its count, plus statistics
 // (tiles = ceil(capacity / pt_compact_tile_slots()) + 1: one workgroup per tile of ballot words)

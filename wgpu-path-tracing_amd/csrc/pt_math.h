@@ -89,6 +89,26 @@ PT_DEV uint32_t f2u(float f) {
     return (uint32_t)f;
 }
 
+// Moller-Trumbore, pt.wgsl:128-158; returns t (> 1e-6) or -1. Straight-line: the reference's four early returns
+// (:134, :143, :151, :157) are folded into one predicate with the same NaN behaviour (a NaN never
+// triggers an early return there, and fails the final t > EPSILON here as there). e1 = v1 - v0, e2 = v2 - v0.
+// Used by the traversal kernels for every candidate and by `shade` to rebuild (u, v) of the closest hit from its
+// triangle (the hit record carries only t and the triangle): same function, same operands, same bits.
+PT_DEV float tri_test(v3 v0, v3 e1, v3 e2, v3 o, v3 d, float &uo, float &vo) {
+    v3 h = cross3(d, e2);
+    float a = dot3(e1, h);
+    float f = 1.0f / a;
+    v3 sv = sub3(o, v0);
+    float u = f * dot3(sv, h);
+    v3 q = cross3(sv, e1);
+    float v = f * dot3(d, q);
+    float t = f * dot3(e2, q);
+    bool reject = (__builtin_fabsf(a) < PT_EPS) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f);
+    bool ok = !reject & (t > PT_EPS);
+    uo = u; vo = v;
+    return ok ? t : -1.0f;
+}
+
 // ---- RNG: src/shader/random.wgsl:3-16 ---------------------------------------
 PT_DEV uint32_t rng_seed(uint32_t x, uint32_t y, uint32_t frame) { return x + y * 1000u + frame * 100000u; }
 PT_DEV uint32_t rng_word(uint32_t &st) {

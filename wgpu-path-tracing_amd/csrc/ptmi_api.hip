@@ -48,7 +48,7 @@ struct ptmi_ctx {
     // wavefront batch buffers
     size_t cap = 0;
     DevPaths paths{};
-    float4 *hits = nullptr;
+    float2 *hits = nullptr;
     DevShadow sh{};
     uint32_t *queue[2] = {nullptr, nullptr}, *sq = nullptr;
     uint64_t *alive = nullptr, *shadowm = nullptr, *octm = nullptr;   // octm: 3 x words (ray_sort)
@@ -137,7 +137,7 @@ struct Timed {
 };
 
 void free_batch(ptmi_ctx *c) {
-    dfree(c->paths.O); dfree(c->paths.D); dfree(c->paths.T); dfree(c->paths.L);
+    dfree(c->paths.O); dfree(c->paths.D); dfree(c->paths.C); dfree(c->paths.L);
     dfree(c->hits); dfree(c->sh.SO); dfree(c->sh.SD); dfree(c->sh.SC);
     dfree(c->queue[0]); dfree(c->queue[1]); dfree(c->sq); dfree(c->alive); dfree(c->shadowm); dfree(c->octm); dfree(c->word_off); dfree(c->d_occ);
     c->cap = 0;
@@ -151,8 +151,8 @@ int ensure_capacity(ptmi_ctx *c, size_t n) {
     size_t words = cap / 64 + 1;
     size_t tiles = cap / pt_compact_tile_slots() + 2;
     HIP_TRY(c, hipMalloc(&c->paths.O, cap * 16)); HIP_TRY(c, hipMalloc(&c->paths.D, cap * 16));
-    HIP_TRY(c, hipMalloc(&c->paths.T, cap * 16)); HIP_TRY(c, hipMalloc(&c->paths.L, cap * 16));
-    HIP_TRY(c, hipMalloc(&c->hits, cap * 16));
+    HIP_TRY(c, hipMalloc(&c->paths.C, cap * 8)); HIP_TRY(c, hipMalloc(&c->paths.L, cap * 16));
+    HIP_TRY(c, hipMalloc(&c->hits, cap * 8));
     HIP_TRY(c, hipMalloc(&c->sh.SO, cap * 16)); HIP_TRY(c, hipMalloc(&c->sh.SD, cap * 16));
     HIP_TRY(c, hipMalloc(&c->sh.SC, cap * 16));
     HIP_TRY(c, hipMalloc(&c->queue[0], cap * 4)); HIP_TRY(c, hipMalloc(&c->queue[1], cap * 4));
@@ -727,12 +727,15 @@ int ptmi_debug_intersect(ptmi_ctx *c, uint32_t n, const float *o3, const float *
     if (c->opt.traversal == PTMI_TRAVERSAL_LDS && cfg.variant != PT_VARIANT_LDS)
         return fail(c, PTMI_E_UNSUPPORTED, "scene does not fit in LDS");
     pt_launch_extend(c->stream, c->n_cu * 8, cfg, c->sc, c->paths, nullptr, &c->counts[0], c->hits);
-    std::vector<float4> h(n);
-    HIP_TRY(c, hipMemcpyAsync(h.data(), c->hits, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+    // (u, v) are not part of the hit record: rebuilt exactly as `shade` rebuilds them (into the C stream, unused here)
+    pt_launch_hit_uv(c->stream, n, c->sc, c->paths, c->hits, c->paths.C);
+    std::vector<float2> h(n), uv(n);
+    HIP_TRY(c, hipMemcpyAsync(h.data(), c->hits, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(uv.data(), c->paths.C, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     for (uint32_t i = 0; i < n; i++) {
-        t[i] = h[i].x; u[i] = h[i].y; v[i] = h[i].z; std::memcpy(&tri[i], &h[i].w, 4);
+        t[i] = h[i].x; u[i] = uv[i].x; v[i] = uv[i].y; std::memcpy(&tri[i], &h[i].y, 4);
     }
     return PTMI_OK;
 }

@@ -50,12 +50,16 @@ PT_DEV v4 texture_color(const DevScene &sc, const ptmi_atlas_rect &tx, float uvx
     return atlas_load(sc, f2u(ax), f2u(ay));
 }
 
-// rayTriangleIntersect, pt.wgsl:159-226, for the closest hit only
-PT_DEV HitInfo make_hitinfo(const DevScene &sc, v3 ro, v3 rd, float t, float u, float v, uint32_t tri) {
+// rayTriangleIntersect, pt.wgsl:159-226, for the closest hit only. The hit record carries (t, triangle); the barycentric
+// (u, v) are the ones `extend` computed when it accepted the hit — recomputed here by the same tri_test on the same
+// operands (e1, e2 are the same single IEEE subtractions the traversal image was built with, ptmi_api.hip).
+PT_DEV HitInfo make_hitinfo(const DevScene &sc, v3 ro, v3 rd, float t, uint32_t tri) {
     HitInfo hi;
     const ptmi_triangle &T = sc.tris[tri];
     v3 v0 = ld3(T.v0);
     v3 e1 = sub3(ld3(T.v1), v0), e2 = sub3(ld3(T.v2), v0);
+    float u, v;
+    (void)tri_test(v0, e1, e2, ro, rd, u, v);
     hi.t = t;
     hi.position = madd3(rd, t, ro);
     float w = 1.0f - u - v;
@@ -276,7 +280,7 @@ constexpr int SBLOCK = 256;
 
 __global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const uint32_t *__restrict__ queue,
                                                   const uint32_t *__restrict__ count_ptr,
-                                                  const float4 *__restrict__ hits, DevShadow S,
+                                                  const float2 *__restrict__ hits, DevShadow S,
                                                   uint64_t *__restrict__ alive_mask,
                                                   uint64_t *__restrict__ shadow_mask, ShadeParams sp) {
     const uint32_t count = *count_ptr;
@@ -287,13 +291,14 @@ __global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const
         bool neg_x = false, neg_y = false, neg_z = false;          // ray_sort: octant of the new direction
         if (i < count) {
             const uint32_t p = queue ? queue[i] : i;
-            const float4 h4 = hits[i];
-            if (!(h4.x < 0.0f)) {                                            // pt.wgsl:646: miss adds zero
+            const float2 h2 = hits[i];
+            if (!(h2.x < 0.0f)) {                                            // pt.wgsl:646: miss adds zero
                 const float4 o4 = P.O[p], d4 = P.D[p];
                 uint32_t rng = __float_as_uint(o4.w);
                 const v3 ro = xyz(o4), rd = xyz(d4);
-                v3 thr = sp.bounce == 0u ? mk3(1.0f, 1.0f, 1.0f) : xyz(P.T[p]);     // pt.wgsl:639; raygen stores no T
-                const HitInfo hit = make_hitinfo(sc, ro, rd, h4.x, h4.y, h4.z, __float_as_uint(h4.w));
+                v3 thr = mk3(1.0f, 1.0f, 1.0f);                                      // pt.wgsl:639; raygen stores no throughput
+                if (sp.bounce != 0u) { const float2 c2 = P.C[p]; thr = mk3(d4.w, c2.x, c2.y); }
+                const HitInfo hit = make_hitinfo(sc, ro, rd, h2.x, __float_as_uint(h2.y));
                 if (hit.emission.x > 0.0f || hit.emission.y > 0.0f || hit.emission.z > 0.0f) {   // pt.wgsl:652-658
                     float att = 1.0f / (1.0f + hit.t * hit.t);
                     float k = hit.emissive_strength;
@@ -341,8 +346,8 @@ __global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const
                         if (alive && sp.bounce + 1u < sp.max_bounces) {
                             neg_x = nd.x < 0.0f; neg_y = nd.y < 0.0f; neg_z = nd.z < 0.0f;
                             P.O[p] = make_float4(no.x, no.y, no.z, __uint_as_float(rng));
-                            P.D[p] = make_float4(nd.x, nd.y, nd.z, 0.0f);
-                            P.T[p] = make_float4(thr.x, thr.y, thr.z, 0.0f);
+                            P.D[p] = make_float4(nd.x, nd.y, nd.z, thr.x);
+                            P.C[p] = make_float2(thr.y, thr.z);
                         }
                     }
                 }
@@ -377,8 +382,28 @@ __global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const
 #define PT_LAUNCH_SHADE pt_launch_shade
 #endif
 void PT_LAUNCH_SHADE(hipStream_t s, int blocks, const DevScene &sc, DevPaths p, const uint32_t *queue,
-                     const uint32_t *count, const float4 *hits, DevShadow sh, uint64_t *alive_mask,
+                     const uint32_t *count, const float2 *hits, DevShadow sh, uint64_t *alive_mask,
                      uint64_t *shadow_mask, ShadeParams sp) {
     hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(SBLOCK), 0, s, sc, p, queue, count, hits, sh, alive_mask,
                        shadow_mask, sp);
 }
+
+#ifndef PT_SHADE_FAST
+namespace {
+__global__ void k_hit_uv(uint32_t n, DevScene sc, DevPaths P, const float2 *__restrict__ hits, float2 *__restrict__ uv) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 h = hits[i];
+    float u = 0.0f, v = 0.0f;
+    if (!(h.x < 0.0f)) {
+        const ptmi_triangle &T = sc.tris[__float_as_uint(h.y)];
+        const v3 v0 = ld3(T.v0);
+        (void)tri_test(v0, sub3(ld3(T.v1), v0), sub3(ld3(T.v2), v0), xyz(P.O[i]), xyz(P.D[i]), u, v);
+    }
+    uv[i] = make_float2(u, v);
+}
+}  // namespace
+void pt_launch_hit_uv(hipStream_t s, uint32_t n, const DevScene &sc, DevPaths p, const float2 *hits, float2 *uv) {
+    hipLaunchKernelGGL(k_hit_uv, dim3((n + 255) / 256), dim3(256), 0, s, n, sc, p, hits, uv);
+}
+#endif

@@ -221,38 +221,20 @@ PT_DEV bool slab(float bx0, float by0, float bz0, float bx1, float by1, float bz
     return tmax >= tmin && tmax >= 0.0f;
 }
 
-// pt.wgsl:128-158; returns t (> 1e-6) or -1. Straight-line: the reference's four early returns
-// (:134, :143, :151, :157) are folded into one predicate with the same NaN behaviour (a NaN never
-// triggers an early return there, and fails the final t > EPSILON here as there).
-PT_DEV float tri_test(v3 v0, v3 e1, v3 e2, v3 o, v3 d, float &uo, float &vo) {
-    v3 h = cross3(d, e2);
-    float a = dot3(e1, h);
-    float f = 1.0f / a;
-    v3 sv = sub3(o, v0);
-    float u = f * dot3(sv, h);
-    v3 q = cross3(sv, e1);
-    float v = f * dot3(d, q);
-    float t = f * dot3(e2, q);
-    bool reject = (__builtin_fabsf(a) < PT_EPS) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f);
-    bool ok = !reject & (t > PT_EPS);
-    uo = u; vo = v;
-    return ok ? t : -1.0f;
-}
-
 // distance beyond which a box cannot hold a nearer hit; the slack covers the
 // rounding difference between a slab entry distance and a triangle's own t
 PT_DEV float cull_limit(float t) { return fma1(t, 1.001f, 1e-4f); }
 
-struct Hit { float t, u, v; uint32_t tri; };
+struct Hit { float t; uint32_t tri; };      // (u, v) are not kept: `shade` rebuilds them from the triangle (pt_math.h tri_test)
 
-PT_DEV float4 pack_hit(const Hit &h) {
-    if (h.tri == PT_REF_NONE) return make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(PT_REF_NONE));
-    return make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
+PT_DEV float2 pack_hit(const Hit &h) {
+    if (h.tri == PT_REF_NONE) return make_float2(-1.0f, __uint_as_float(PT_REF_NONE));
+    return make_float2(h.t, __uint_as_float(h.tri));
 }
 
 // ---- ray sources / result sinks of the two kernels ---------------------------------
 struct ExtendIO {
-    const float4 *O, *D; const uint32_t *queue; float4 *hits;
+    const float4 *O, *D; const uint32_t *queue; float2 *hits;
     PT_DEV void fetch(uint32_t slot, v3 &o, v3 &d, float &tlim) const {
         uint32_t p = queue ? queue[slot] : slot;
         float4 o4 = O[p], d4 = D[p];
@@ -324,7 +306,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
     v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), inv = mk3(0, 0, 0);
     float tlim = 0.0f, limit = __builtin_inff();
     typename Mem::RayK rk{};
-    Hit best; best.t = __builtin_inff(); best.u = best.v = 0.0f; best.tri = PT_REF_NONE;
+    Hit best; best.t = __builtin_inff(); best.tri = PT_REF_NONE;
 
     for (;;) {
         uint64_t act = ballot(active);
@@ -337,7 +319,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                 slot = vslot;
                 io.fetch(slot, o, d, tlim);
                 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                best.t = __builtin_inff(); best.u = best.v = 0.0f; best.tri = PT_REF_NONE;
+                best.t = __builtin_inff(); best.tri = PT_REF_NONE;
                 sp = bot; lp = top; spn = 0u; cur = PT_REF_NONE;
                 limit = (ANY && CULL) ? cull_limit(tlim) : __builtin_inff();      // NaN for a directional light: never culls
                 const bool regular = __builtin_isfinite(inv.x) & __builtin_isfinite(inv.y) & __builtin_isfinite(inv.z) &
@@ -393,8 +375,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                             occluded = occluded | (hit & !(t >= tlim));
                         } else {
                             const bool better = hit & ((t < best.t) | ((t == best.t) & (ti < best.tri)));
-                            best.t = better ? t : best.t; best.u = better ? u : best.u;
-                            best.v = better ? v : best.v; best.tri = better ? ti : best.tri;
+                            best.t = better ? t : best.t; best.tri = better ? ti : best.tri;
                             if (CULL) limit = better ? cull_limit(t) : limit;
                         }
                     }
@@ -597,7 +578,7 @@ void launch(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene
 }  // namespace
 
 void pt_launch_extend(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, DevPaths p,
-                      const uint32_t *queue, const uint32_t *count, float4 *hits) {
+                      const uint32_t *queue, const uint32_t *count, float2 *hits) {
     ExtendIO io{p.O, p.D, queue, hits};
     if (cfg.cull) launch<MODE_EXTEND, true>(s, blocks, cfg, sc, io, count);
     else launch<MODE_EXTEND, false>(s, blocks, cfg, sc, io, count);
