@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--perf-mode", type=int, default=0, help="library option perf_mode (0 = parity arithmetic, the headline)")
     ap.add_argument("--sort", type=int, default=None, help="library option ray_sort (default: the library's)")
+    ap.add_argument("--overlap", type=int, default=None, help="library option overlap (0: one stream; default: the library's)")
     ap.add_argument("--keep-reference-tree", action="store_true",
                     help="walk the BVH exactly as uploaded instead of the hierarchy rebuilt over its leaves")
     ap.add_argument("--rehearse", action="store_true",
@@ -237,6 +238,8 @@ def main():
         extra["perf_mode"] = args.perf_mode
     if args.sort is not None:
         extra["ray_sort"] = args.sort
+    if args.overlap is not None:
+        extra["overlap"] = args.overlap
     ctx.set_options(max_bounces=cfg["bounces"], do_mis=mis, frames_per_batch=args.frames_per_batch, traversal=trav, cull=1,
                     timing=args.timing, **extra, **shard.strip_options(world, rank, strip))
 
@@ -299,7 +302,7 @@ def main():
         msamples = segments / dt / 1e6
         b_seg = pipeline_bytes_per_segment(mis, mean_len)
         is_profiled = (not overridden and world == 1 and args.traversal == "auto" and args.steps is None
-                       and not args.perf_mode and args.sort is None and not args.keep_reference_tree
+                       and not args.perf_mode and args.sort is None and args.overlap is None and not args.keep_reference_tree
                        and args.frames_per_batch == 0)
         traffic, traffic_src = pmc_traffic(args.config, is_profiled)
 

@@ -74,7 +74,11 @@ typedef struct ptmi_options {
     uint32_t ray_sort;          /* 0: queues keep ascending path order; 1: within each compaction tile (16384 slots) surviving rays
                                    are grouped by direction octant before the next traversal (coherent waves; results unchanged);
                                    2 = library default (currently the measured better of the two) */
-    uint32_t reserved[2];
+    uint32_t overlap;           /* 0: every kernel of a dispatch on the context's one stream, in order; 1: the any-hit `shadow` kernel of
+                                   bounce b runs on a second (lower-priority) stream beside `extend` / `shade` of bounce b + 1 — it is
+                                   the only kernel that adds to the radiance then, in bounce order, so results are unchanged;
+                                   2 = library default (currently 1 when next-event estimation is on) */
+    uint32_t reserved[1];
 } ptmi_options;
 
 typedef struct ptmi_stats {

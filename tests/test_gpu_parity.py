@@ -280,6 +280,32 @@ def test_ray_sort_is_invisible(gpu_ctx, oracle, scene_factory, name):
     gpu_ctx.set_options(ray_sort=2, frames_per_batch=0)
 
 
+@pytest.mark.parametrize("name,trav", [("cornell", 0), ("feature_box", 0), ("cornell_spheres", 1)])
+def test_overlapped_shadow_stream_is_invisible(gpu_ctx, oracle, scene_factory, name, trav):
+    """options.overlap: with it the shadow kernel of bounce b runs on a second stream beside the next bounce, emissive hits
+    reach the radiance through records, and the record buffers alternate; without it everything is on one stream and
+    `shade` adds emission itself. Both must give the oracle's bits and counters — also over several batches in one
+    dispatch (frames_per_batch 2 of 5 frames: the buffers and events are reused), 1 and 2 bounces (fewer bounces than
+    buffers) and with the global traversal variant (its own spill area on the side stream)."""
+    sc = scene_factory(name)
+    W, H, frames = 160, 100, 5
+    cam = layout.make_camera(W, H)
+    gpu_ctx.upload_scene(sc)
+    for bounces in (8, 2, 1):
+        ref, ost = oracle.render(sc, cam, frames, max_bounces=bounces, do_mis=1)
+        for overlap, fpb in ((1, 0), (1, 2), (0, 0)):
+            gpu_ctx.resize(W, H)
+            gpu_ctx.set_options(max_bounces=bounces, do_mis=1, tile_y0=0, tile_y1=0, tile_parts=0, frames_per_batch=fpb, cull=1,
+                                traversal=trav, overlap=overlap, timing=3)
+            gpu_ctx.reset_stats()
+            gpu_ctx.dispatch(cam, frames)
+            got = gpu_ctx.read_output()
+            st = gpu_ctx.stats()
+            assert (st.segments, st.shadow_rays, st.paths) == (ost.segments, ost.shadow_rays, ost.paths)
+            assert_same_floats(got, ref, f"radiance ({name}, overlap {overlap}, frames_per_batch {fpb}, {bounces} bounces)")
+    gpu_ctx.set_options(overlap=2, frames_per_batch=0, traversal=0, max_bounces=8, timing=0)
+
+
 def test_errors_are_loud(gpu_ctx, scene_factory):
     from ptmi import native
     sc = scene_factory("cornell")

@@ -70,6 +70,10 @@ struct ShadeParams {
     unsigned long long *stats;          // [1] += next-event samples counted but not traced (zero contribution)
     uint64_t *octant_masks;             // ray_sort: per 64 slots the sign bits of the survivors' new direction, three arrays
     uint32_t octant_stride;             //           octant_stride words apart (x, y, z); NULL: not wanted
+    uint32_t emit_records;              // 1: an emissive hit does not add to L here; it leaves a record (SO.w = -2: nothing to trace)
+                                        //    that `shadow` adds like an unoccluded light sample — all additions to L then happen in
+                                        //    that one kernel, in bounce order, and `shadow` can run beside the next bounce's kernels.
+                                        //    stats[3] += such records (they are not shadow rays)
 };
 
 enum { PT_VARIANT_GLOBAL = 1, PT_VARIANT_LDS = 2, PT_VARIANT_LDS_NODES = 3 };

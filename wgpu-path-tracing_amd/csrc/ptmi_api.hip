@@ -29,6 +29,8 @@ constexpr size_t kMaxPendingEvents = 4096;        // a caller that never synchro
 struct ptmi_ctx {
     int device = 0, n_cu = 256;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t side_stream = nullptr;                 // `shadow` of bounce b beside the kernels of bounce b + 1 (options.overlap)
+    hipEvent_t ev_ready = nullptr, ev_shadow[2] = {nullptr, nullptr};
     mutable std::string err;
     ptmi_options opt{};
 
@@ -49,13 +51,14 @@ struct ptmi_ctx {
     size_t cap = 0;
     DevPaths paths{};
     float2 *hits = nullptr;
-    DevShadow sh{};
-    uint32_t *queue[2] = {nullptr, nullptr}, *sq = nullptr;
+    DevShadow sh[2]{};                                 // shadow records, double-buffered by bounce parity (overlap)
+    uint32_t *queue[2] = {nullptr, nullptr}, *sq[2] = {nullptr, nullptr};
     uint64_t *alive = nullptr, *shadowm = nullptr, *octm = nullptr;   // octm: 3 x words (ray_sort)
     size_t mask_words = 0;
     uint32_t *word_off = nullptr, *counts = nullptr;
     unsigned long long *d_stats = nullptr;
     uint32_t *d_spill = nullptr;          // node-stack overflow of the global traversal variant (128 MiB on 256 CUs, allocated by ptmi_create)
+    uint32_t *d_spill_side = nullptr;     // ... of the `shadow` kernel when it runs beside `extend` (allocated on first use)
     uint8_t *d_occ = nullptr;
     float4 *d_blit_f32 = nullptr; uint32_t *d_blit_u8 = nullptr; size_t blit_px = 0;   // canvas staging of ptmi_blit, kept between calls
 
@@ -84,7 +87,7 @@ template <class T> void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; }
 
 void default_options(ptmi_options &o) {
     std::memset(&o, 0, sizeof o);
-    o.max_bounces = 8; o.do_mis = 1; o.cull = 1; o.traversal = PTMI_TRAVERSAL_AUTO; o.ray_sort = 2;
+    o.max_bounces = 8; o.do_mis = 1; o.cull = 1; o.traversal = PTMI_TRAVERSAL_AUTO; o.ray_sort = 2; o.overlap = 2;
 }
 
 hipEvent_t get_event(ptmi_ctx *c) {
@@ -125,12 +128,13 @@ void drain_completed_events(ptmi_ctx *c) {
 
 struct Timed {
     ptmi_ctx *c; hipEvent_t a = nullptr, b = nullptr; int kind; bool on;
-    Timed(ptmi_ctx *c_, int kind_, bool on_) : c(c_), kind(kind_), on(on_) {
-        if (on) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); }
+    hipStream_t st;
+    Timed(ptmi_ctx *c_, int kind_, bool on_, hipStream_t st_ = nullptr) : c(c_), kind(kind_), on(on_), st(st_ ? st_ : c_->stream) {
+        if (on) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, st); }
     }
     ~Timed() {
         if (!on) return;
-        (void)hipEventRecord(b, c->stream);
+        (void)hipEventRecord(b, st);
         c->pending.push_back({a, b, kind});
         if (c->pending.size() > kMaxPendingEvents) drain_completed_events(c);
     }
@@ -138,14 +142,16 @@ struct Timed {
 
 void free_batch(ptmi_ctx *c) {
     dfree(c->paths.O); dfree(c->paths.D); dfree(c->paths.C); dfree(c->paths.L);
-    dfree(c->hits); dfree(c->sh.SO); dfree(c->sh.SD); dfree(c->sh.SC);
-    dfree(c->queue[0]); dfree(c->queue[1]); dfree(c->sq); dfree(c->alive); dfree(c->shadowm); dfree(c->octm); dfree(c->word_off); dfree(c->d_occ);
+    dfree(c->hits);
+    for (int k = 0; k < 2; k++) { dfree(c->sh[k].SO); dfree(c->sh[k].SD); dfree(c->sh[k].SC); dfree(c->sq[k]); }
+    dfree(c->queue[0]); dfree(c->queue[1]); dfree(c->alive); dfree(c->shadowm); dfree(c->octm); dfree(c->word_off); dfree(c->d_occ);
     c->cap = 0;
 }
 
 int ensure_capacity(ptmi_ctx *c, size_t n) {
     if (n <= c->cap) return PTMI_OK;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->side_stream) HIP_TRY(c, hipStreamSynchronize(c->side_stream));
     free_batch(c);
     size_t cap = (n + 1023) & ~(size_t)1023;
     size_t words = cap / 64 + 1;
@@ -153,10 +159,11 @@ int ensure_capacity(ptmi_ctx *c, size_t n) {
     HIP_TRY(c, hipMalloc(&c->paths.O, cap * 16)); HIP_TRY(c, hipMalloc(&c->paths.D, cap * 16));
     HIP_TRY(c, hipMalloc(&c->paths.C, cap * 8)); HIP_TRY(c, hipMalloc(&c->paths.L, cap * 16));
     HIP_TRY(c, hipMalloc(&c->hits, cap * 8));
-    HIP_TRY(c, hipMalloc(&c->sh.SO, cap * 16)); HIP_TRY(c, hipMalloc(&c->sh.SD, cap * 16));
-    HIP_TRY(c, hipMalloc(&c->sh.SC, cap * 16));
+    for (int k = 0; k < 2; k++) {
+        HIP_TRY(c, hipMalloc(&c->sh[k].SO, cap * 16)); HIP_TRY(c, hipMalloc(&c->sh[k].SD, cap * 16));
+        HIP_TRY(c, hipMalloc(&c->sh[k].SC, cap * 16)); HIP_TRY(c, hipMalloc(&c->sq[k], cap * 4));
+    }
     HIP_TRY(c, hipMalloc(&c->queue[0], cap * 4)); HIP_TRY(c, hipMalloc(&c->queue[1], cap * 4));
-    HIP_TRY(c, hipMalloc(&c->sq, cap * 4));
     HIP_TRY(c, hipMalloc(&c->alive, words * 8)); HIP_TRY(c, hipMalloc(&c->shadowm, words * 8));
     HIP_TRY(c, hipMalloc(&c->octm, 3 * words * 8)); c->mask_words = words;
     HIP_TRY(c, hipMalloc(&c->word_off, 2 * tiles * 4));
@@ -366,6 +373,16 @@ int ptmi_create(int device_ordinal, ptmi_ctx **out) {
         delete c; return fail(nullptr, PTMI_E_HIP, "hipStreamCreate failed");
     }
     c->stream = c->own_stream;
+    {
+        int lo = 0, hi = 0;                                  // the side stream yields to the main one
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, lo) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_shadow[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_shadow[1], hipEventDisableTiming) != hipSuccess) {
+            ptmi_destroy(c); return fail(nullptr, PTMI_E_HIP, "side stream / event creation failed");
+        }
+    }
     if (hipMalloc(&c->counts, 80 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(&c->d_stats, kStatsWords * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(c->d_stats, 0, kStatsWords * sizeof(unsigned long long)) != hipSuccess ||
@@ -380,12 +397,17 @@ int ptmi_destroy(ptmi_ctx *c) {
     if (!c) return PTMI_E_INVALID;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
     drain_events(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     free_batch(c);
     dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_atlas); dfree(c->d_wnodes); dfree(c->d_tripos);
     dfree(c->d_fast_wnodes); dfree(c->d_qnodes); dfree(c->d_leaf_stream);
     dfree(c->d_out_own); dfree(c->counts); dfree(c->d_stats); dfree(c->d_spill); dfree(c->d_blit_f32); dfree(c->d_blit_u8);
+    dfree(c->d_spill_side);
+    if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+    for (hipEvent_t e : c->ev_shadow) if (e) (void)hipEventDestroy(e);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return PTMI_OK;
@@ -500,6 +522,7 @@ int ptmi_set_options(ptmi_ctx *c, const ptmi_options *o) {
         return fail(c, PTMI_E_INVALID, "tile_part %u is not below tile_parts %u", o->tile_part, o->tile_parts);
     if (o->perf_mode > 1) return fail(c, PTMI_E_INVALID, "unknown perf_mode %u", o->perf_mode);
     if (o->ray_sort > 2) return fail(c, PTMI_E_INVALID, "unknown ray_sort %u", o->ray_sort);
+    if (o->overlap > 2) return fail(c, PTMI_E_INVALID, "unknown overlap %u", o->overlap);
     c->opt = *o;
     return PTMI_OK;
 }
@@ -544,6 +567,17 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     const uint32_t maxb = c->opt.max_bounces;
     const bool sort = c->opt.ray_sort == 1;          // 2 (library default) = off: measured, profiles/README.md
     const bool t1 = c->opt.timing >= 1, t2 = c->opt.timing >= 2, t3 = c->opt.timing >= 3;
+    const bool nee = c->opt.do_mis && c->sc.n_lights > 0;
+    // overlap: `shadow` of bounce b on the side stream, beside extend / shade of bounce b + 1. It is then the only kernel that
+    // adds to L (emissive hits leave a record too, ShadeParams::emit_records), bounce after bounce on one stream, so every
+    // path's sum is formed in the same order as without it. Record buffers alternate by bounce parity; shade(b) waits for
+    // shadow(b - 2), accumulate for the last one.
+    const bool overlap = nee && c->opt.overlap != 0;
+    TraverseConfig cfg_side = cfg_shadow;
+    if (overlap && cfg_shadow.variant == PT_VARIANT_GLOBAL) {           // its own spill area: it runs beside `extend`
+        if (!c->d_spill_side) HIP_TRY(c, hipMalloc(&c->d_spill_side, pt_spill_bytes(c->n_cu * 8)));
+        cfg_side.spill = c->d_spill_side;
+    }
     {
         Timed td(c, 0, t1);
         for (uint32_t f0 = 0; f0 < n_frames; f0 += F) {
@@ -553,23 +587,35 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
             int cur = 0;
             for (uint32_t b = 0; b < maxb; b++) {
                 const uint32_t *q = b == 0 ? nullptr : c->queue[cur];      // bounce 0: slot i holds path i
+                const int par = overlap ? (int)(b & 1u) : 0;
                 { Timed t(c, 1, t2); pt_launch_extend(c->stream, blocks, cfg, c->sc, c->paths, q, &c->counts[b], c->hits); }
                 const bool last = b + 1 == maxb;
                 uint64_t *octm = (sort && !last) ? c->octm : nullptr;
+                if (overlap && b >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_shadow[par], 0));      // its records are read
                 { Timed t(c, 2, t3);
                   (c->opt.perf_mode ? pt_launch_shade_fast : pt_launch_shade)(
-                      c->stream, blocks, c->sc, c->paths, q, &c->counts[b], c->hits, c->sh, c->alive, c->shadowm,
-                      ShadeParams{b, maxb, c->opt.do_mis, c->d_stats, octm, (uint32_t)c->mask_words}); }
-                const bool nee = c->opt.do_mis && c->sc.n_lights > 0;
+                      c->stream, blocks, c->sc, c->paths, q, &c->counts[b], c->hits, c->sh[par], c->alive, c->shadowm,
+                      ShadeParams{b, maxb, c->opt.do_mis, c->d_stats, octm, (uint32_t)c->mask_words, overlap ? 1u : 0u}); }
                 { Timed t(c, 5, t3);
                   pt_launch_compact(c->stream, tiles, q, &c->counts[b], c->alive, nee ? c->shadowm : nullptr,
-                                    c->word_off, c->queue[cur ^ 1], &c->counts[b + 1], c->sq, &c->counts[kShadowCount],
+                                    c->word_off, c->queue[cur ^ 1], &c->counts[b + 1], c->sq[par], &c->counts[kShadowCount + par],
                                     c->d_stats, b, last ? 0 : 1, octm, (uint32_t)c->mask_words); }
-                if (nee) {
+                if (overlap) {
+                    HIP_TRY(c, hipEventRecord(c->ev_ready, c->stream));
+                    HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->ev_ready, 0));
+                    { Timed t(c, 3, t3, c->side_stream);
+                      pt_launch_shadow(c->side_stream, blocks, cfg_side, c->sc, c->paths, c->sh[par], c->sq[par],
+                                       &c->counts[kShadowCount + par], nullptr); }
+                    HIP_TRY(c, hipEventRecord(c->ev_shadow[par], c->side_stream));
+                } else if (nee) {
                     Timed t(c, 3, t3);
-                    pt_launch_shadow(c->stream, blocks, cfg_shadow, c->sc, c->paths, c->sh, c->sq, &c->counts[kShadowCount], nullptr);
+                    pt_launch_shadow(c->stream, blocks, cfg_shadow, c->sc, c->paths, c->sh[0], c->sq[0], &c->counts[kShadowCount], nullptr);
                 }
                 cur ^= 1;
+            }
+            if (overlap) {                                               // all additions to L are in before it is folded
+                HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_shadow[(maxb - 1) & 1u], 0));
+                if (maxb >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_shadow[maxb & 1u], 0));
             }
             { Timed t(c, 6, t3); pt_launch_accumulate(c->stream, blocks, band, frame0, fb, c->paths.L, c->d_out); }
         }
@@ -666,7 +712,7 @@ int ptmi_get_stats(ptmi_ctx *c, ptmi_stats *out) {
     drain_events(c);
     unsigned long long h[kStatsWords];
     HIP_TRY(c, hipMemcpy(h, c->d_stats, sizeof h, hipMemcpyDeviceToHost));
-    c->st.segments = h[0]; c->st.shadow_rays = h[1]; c->st.shadow_traced = h[2];
+    c->st.segments = h[0]; c->st.shadow_rays = h[1] - h[3]; c->st.shadow_traced = h[2] - h[3];      // h[3]: records of emissive hits
     for (int i = 0; i < 64; i++) c->st.segments_by_bounce[i] = h[8 + i];
     c->st.bvh_depth = c->bvh_depth;
     *out = c->st;
@@ -748,11 +794,11 @@ int ptmi_debug_occluded(ptmi_ctx *c, uint32_t n, const float *o3, const float *d
     HIP_TRY(c, hipSetDevice(c->device));
     rc = ensure_capacity(c, n);
     if (rc) return rc;
-    rc = upload_rays(c, n, o3, d3, dist, c->sh.SO, c->sh.SD);
+    rc = upload_rays(c, n, o3, d3, dist, c->sh[0].SO, c->sh[0].SD);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(&c->counts[0], &n, 4, hipMemcpyHostToDevice, c->stream));
     TraverseConfig cfg = traverse_config(c, false);
-    pt_launch_shadow(c->stream, c->n_cu * 8, cfg, c->sc, c->paths, c->sh, nullptr, &c->counts[0], c->d_occ);
+    pt_launch_shadow(c->stream, c->n_cu * 8, cfg, c->sc, c->paths, c->sh[0], nullptr, &c->counts[0], c->d_occ);
     HIP_TRY(c, hipMemcpyAsync(occ, c->d_occ, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());

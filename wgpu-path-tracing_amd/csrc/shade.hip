@@ -284,10 +284,10 @@ __global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const
                                                   uint64_t *__restrict__ alive_mask,
                                                   uint64_t *__restrict__ shadow_mask, ShadeParams sp) {
     const uint32_t count = *count_ptr;
-    uint32_t n_skipped = 0;                 // lane 0 of each wave: one atomic per wave at the end
+    uint32_t n_skipped = 0, n_emitted = 0;  // lane 0 of each wave: one atomic per wave at the end
     for (uint32_t base = blockIdx.x * SBLOCK; base < count; base += gridDim.x * SBLOCK) {
         const uint32_t i = base + threadIdx.x;
-        bool alive = false, shadow = false, skipped = false;
+        bool alive = false, shadow = false, skipped = false, emitted = false;
         bool neg_x = false, neg_y = false, neg_z = false;          // ray_sort: octant of the new direction
         if (i < count) {
             const uint32_t p = queue ? queue[i] : i;
@@ -302,9 +302,16 @@ __global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const
                 if (hit.emission.x > 0.0f || hit.emission.y > 0.0f || hit.emission.z > 0.0f) {   // pt.wgsl:652-658
                     float att = 1.0f / (1.0f + hit.t * hit.t);
                     float k = hit.emissive_strength;
-                    float4 l = P.L[p];
-                    P.L[p] = make_float4(l.x + thr.x * hit.emission.x * k * att, l.y + thr.y * hit.emission.y * k * att,
-                                         l.z + thr.z * hit.emission.z * k * att, 0.0f);
+                    const v3 e = mk3(thr.x * hit.emission.x * k * att, thr.y * hit.emission.y * k * att, thr.z * hit.emission.z * k * att);
+                    if (sp.emit_records) {          // the path ends here: its last addition to L, made by `shadow` in bounce order
+                        S.SO[i] = make_float4(0.0f, 0.0f, 0.0f, -2.0f);
+                        S.SD[i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(p));
+                        S.SC[i] = make_float4(e.x, e.y, e.z, 0.0f);
+                        shadow = true; emitted = true;
+                    } else {
+                        float4 l = P.L[p];
+                        P.L[p] = make_float4(l.x + e.x, l.y + e.y, l.z + e.z, 0.0f);
+                    }
                 } else {
                     if (sp.do_mis && sc.n_lights > 0u && hit.transmission == 0.0f && hit.is_front) {   // pt.wgsl:661
                         LightSample ls = sample_light(sc, rng, hit.position);
@@ -353,11 +360,12 @@ __global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const
                 }
             }
         }
-        const uint64_t am = __ballot(alive), sm = __ballot(shadow), zm = __ballot(skipped);
+        const uint64_t am = __ballot(alive), sm = __ballot(shadow), zm = __ballot(skipped), em = __ballot(emitted);
         if ((threadIdx.x & 63u) == 0u && i < count) {
             alive_mask[i >> 6] = am;
             shadow_mask[i >> 6] = sm;
             n_skipped += (uint32_t)__popcll(zm);
+            n_emitted += (uint32_t)__popcll(em);
         }
         if (sp.octant_masks) {
             const uint64_t bx = __ballot(neg_x), by = __ballot(neg_y), bz = __ballot(neg_z);
@@ -369,6 +377,7 @@ __global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const
         }
     }
     if (n_skipped) atomicAdd(&sp.stats[1], (unsigned long long)n_skipped);
+    if (n_emitted) atomicAdd(&sp.stats[3], (unsigned long long)n_emitted);
 }
 
 }  // namespace

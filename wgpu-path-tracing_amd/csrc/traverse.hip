@@ -235,16 +235,18 @@ PT_DEV float2 pack_hit(const Hit &h) {
 // ---- ray sources / result sinks of the two kernels ---------------------------------
 struct ExtendIO {
     const float4 *O, *D; const uint32_t *queue; float2 *hits;
-    PT_DEV void fetch(uint32_t slot, v3 &o, v3 &d, float &tlim) const {
+    PT_DEV bool fetch(uint32_t slot, v3 &o, v3 &d, float &tlim) const {
         uint32_t p = queue ? queue[slot] : slot;
         float4 o4 = O[p], d4 = D[p];
         o = xyz(o4); d = xyz(d4); tlim = 0.0f;
+        return true;
     }
     PT_DEV void finish(uint32_t slot, const Hit &h, bool) const { hits[slot] = pack_hit(h); }
 };
 struct ShadowIO {
     DevPaths P; DevShadow S; const uint32_t *sq; uint8_t *occluded_out;
-    PT_DEV void fetch(uint32_t &slot, v3 &o, v3 &d, float &tlim) const {
+    // false: nothing to trace — the record of an emissive hit (SO.w = -2, shade.hip), added to L like an unoccluded sample
+    PT_DEV bool fetch(uint32_t &slot, v3 &o, v3 &d, float &tlim) const {
         uint32_t i = sq ? sq[slot] : slot;
         slot = i;                                              // the record's own slot is what finish() needs
         float4 so = S.SO[i], sd = S.SD[i];
@@ -253,6 +255,7 @@ struct ShadowIO {
         // occluded). A directional light (:394) has no distance, any hit occludes, one at t = +inf included: tlim = NaN,
         // and the tests below are written so that NaN means "no limit" (!(t >= NaN) is true, tl > NaN is false).
         tlim = so.w < 0.0f ? __builtin_nanf("") : so.w - PT_EPS * 2.0f;
+        return so.w != -2.0f;
     }
     PT_DEV void finish(uint32_t i, const Hit &, bool occluded) const {
         if (occluded_out) { occluded_out[i] = occluded ? 1 : 0; return; }
@@ -317,7 +320,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
             const uint32_t vslot = ((vi >> 6) * total_waves + gw) * 64u + (vi & 63u);
             if (!active && vi < end && vslot < count) {
                 slot = vslot;
-                io.fetch(slot, o, d, tlim);
+                const bool want = io.fetch(slot, o, d, tlim);
                 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                 best.t = __builtin_inff(); best.tri = PT_REF_NONE;
                 sp = bot; lp = top; spn = 0u; cur = PT_REF_NONE;
@@ -327,7 +330,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                 use_ref = sc.has_fast != 0u && !regular;
                 m.prep(o, inv, rk);
                 float tm;
-                if (sc.root_ref != PT_REF_NONE &&
+                if (want && sc.root_ref != PT_REF_NONE &&
                     slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2],
                          o, inv, tm)) {
                     active = true;

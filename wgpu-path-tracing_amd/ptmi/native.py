@@ -39,7 +39,8 @@ class Options(ctypes.Structure):
                 ("frames_per_batch", ctypes.c_uint32), ("traversal", ctypes.c_uint32),
                 ("cull", ctypes.c_uint32), ("timing", ctypes.c_uint32), ("keep_reference_tree", ctypes.c_uint32),
                 ("tile_parts", ctypes.c_uint32), ("tile_part", ctypes.c_uint32), ("tile_strip", ctypes.c_uint32),
-                ("perf_mode", ctypes.c_uint32), ("ray_sort", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 2)]
+                ("perf_mode", ctypes.c_uint32), ("ray_sort", ctypes.c_uint32), ("overlap", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32 * 1)]
 
 
 class Stats(ctypes.Structure):
