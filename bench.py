@@ -353,6 +353,10 @@ def main():
             "nominal_msamples": round(paths * cfg["bounces"] / dt / 1e6, 3),
             "gpu_ms_rank0": round(st.gpu_ms, 3),
             "kernel_ms_rank0": {k: round(v, 3) for k, v in kernel_ms.items()},
+            # with the shadow kernel on its own stream (library option overlap, the default with next-event estimation) kernels
+            # run beside each other: their HIP-event times then add up to MORE than the dispatch time; --overlap 0 puts
+            # everything on one stream, where the sum must equal it
+            "shadow_overlapped": bool(mis and (args.overlap is None or args.overlap != 0)),
             "kernel_ms_sum_over_gpu_ms": round(sum(kernel_ms.values()) / st.gpu_ms, 4) if st.gpu_ms > 0 else None,
             "upload_ms_rank0": {"wall": round(upload_wall_ms, 2), "library": round(st.upload_ms, 2),
                                 "rebuilt_hierarchy": round(st.upload_tree_ms, 2), "copies": round(st.upload_copy_ms, 2)},

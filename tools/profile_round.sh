@@ -15,6 +15,8 @@ python3 bench.py --config $cfg "$@" > ${pre}_bench.json 2> ${pre}.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt$cfg -- python3 bench.py --config $cfg --no-cpu-baseline "$@" > ${pre}_bench_profiled.json 2>> ${pre}.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pf$cfg -- python3 bench.py --config $cfg --no-cpu-baseline "$@" > /dev/null 2>> ${pre}.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pw$cfg -- python3 bench.py --config $cfg --no-cpu-baseline "$@" > /dev/null 2>> ${pre}.err
+[ $cfg = 1 ] && python3 bench.py --config 1 --no-cpu-baseline --overlap 0 "$@" | python3 -c "
+import sys, json; d = json.loads(sys.stdin.read()); d['cpu_baseline'] = json.load(open('${pre}_bench.json'))['cpu_baseline']; print(json.dumps(d))" > ${pre}_bench_one_stream.json
 cp $(find $out/kt$cfg -name "*kernel_stats.csv" | head -1) ${pre}_kernel_stats.csv
 python3 tools/per_bounce.py $(find $out/kt$cfg -name "*kernel_trace.csv" | head -1) > ${pre}_per_bounce.json || true
 python3 tools/pmc_summary.py --json --commit $commit $(find $out/pf$cfg $out/pw$cfg -name "*counter_collection.csv") > ${pre}_pmc.json

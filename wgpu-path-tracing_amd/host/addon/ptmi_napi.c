@@ -167,6 +167,9 @@ static napi_value js_set_options(napi_env env, napi_callback_info info) {
     o.tile_parts = get_u32_prop(env, argv[1], "tileParts", o.tile_parts);
     o.tile_part = get_u32_prop(env, argv[1], "tilePart", o.tile_part);
     o.tile_strip = get_u32_prop(env, argv[1], "tileStrip", o.tile_strip);
+    o.perf_mode = get_u32_prop(env, argv[1], "perfMode", o.perf_mode);
+    o.ray_sort = get_u32_prop(env, argv[1], "raySort", o.ray_sort);
+    o.overlap = get_u32_prop(env, argv[1], "overlap", o.overlap);
     int rc = ptmi_set_options(ctx, &o);
     if (rc) return throw_ptmi(env, ctx, rc, "ptmi_set_options");
     return NULL;

@@ -22,8 +22,14 @@ export interface SceneBlobs { triangles: ArrayBuffer; materials: ArrayBuffer; bv
 export interface Atlas { data: ArrayBuffer; width: number; height: number; format: 1 | 2; }
 export interface TraceOptions {
   maxBounces?: number; doMis?: number; tileY0?: number; tileY1?: number; framesPerBatch?: number;
-  traversal?: 0 | 1 | 2; cull?: number; timing?: number; keepReferenceTree?: number;
+  traversal?: 0 | 1 | 2 | 3; cull?: number; timing?: number; keepReferenceTree?: number;
   tileParts?: number; tilePart?: number; tileStrip?: number;
+  /** include/ptmi.h: 1 = fast reciprocal / sqrt in `shade` (statistically, not bitwise, the same image); never the default */
+  perfMode?: 0 | 1;
+  /** 0 / 1 / 2 (library default): group each 1024-slot window of the ray queue by direction octant */
+  raySort?: 0 | 1 | 2;
+  /** 0 / 1 / 2 (library default): run the shadow kernel on a second stream beside the next bounce */
+  overlap?: 0 | 1 | 2;
 }
 export interface Stats {
   paths: number; segments: number; shadowRays: number; frames: number; dispatches: number;
