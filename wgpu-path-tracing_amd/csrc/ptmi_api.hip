@@ -306,7 +306,11 @@ TraverseConfig traverse_config(const ptmi_ctx *c, bool closest_hit) {
     const bool node_cache = have && c->bvh_depth + 2 <= 16 &&
                             (size_t)c->sc.n_wnodes * 64 + (size_t)small_stack * 1024 * 4 <= kLdsMax / 2;
     cfg.spill = nullptr; cfg.wgs_per_cu = 2;
-    cfg.quantized = c->opt.traversal != PTMI_TRAVERSAL_GLOBAL_EXACT;
+    // The quantised image pays where node fetches leave the L2 (measured: the 1 M-triangle scene, 67 MB, extend -16 %); a scene
+    // that an XCD's 4 MiB L2 holds is bound by the ALUs, and decoding costs more than the bytes save (cornell_spheres walked
+    // from global memory: shadow +30 %). AUTO decides by size; GLOBAL asks for the quantised image, GLOBAL_EXACT for the exact one.
+    cfg.quantized = c->opt.traversal == PTMI_TRAVERSAL_GLOBAL ||
+                    (c->opt.traversal == PTMI_TRAVERSAL_AUTO && c->lds_scene_bytes > ((size_t)4 << 20));
     if (c->opt.traversal == PTMI_TRAVERSAL_GLOBAL || c->opt.traversal == PTMI_TRAVERSAL_GLOBAL_EXACT) cfg.variant = PT_VARIANT_GLOBAL;
     else if (closest_hit && node_cache && c->opt.traversal == PTMI_TRAVERSAL_AUTO) {   // any-hit: measured 15 % slower with it
         cfg.variant = PT_VARIANT_LDS_NODES; cfg.stack_entries = small_stack;

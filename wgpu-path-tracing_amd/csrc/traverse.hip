@@ -37,7 +37,12 @@ constexpr int MODE_EXTEND = 0, MODE_SHADOW = 1;
 #ifndef PT_REFILL_AT
 #define PT_REFILL_AT 36
 #endif
-constexpr int REFILL_AT = PT_REFILL_AT;   // refill when at most this many of the 64 lanes still hold a ray
+constexpr int REFILL_AT = PT_REFILL_AT;   // refill when at most this many of the 64 lanes still hold a ray (scene in LDS)
+// The kernels that walk the scene from global memory refill earlier: a lane without a ray also means a memory request
+// less in flight. Measured on the 1 M-triangle scene (Msamples/s): 28: 4 404, 36: 4 543, 44: 4 638; Cornell ±1 % throughout.
+#ifndef PT_REFILL_GLOBAL
+#define PT_REFILL_GLOBAL 44
+#endif
 // One vote (two ballots, the refill and completion tests) costs about half a box-pair step, so a stream keeps
 // running for up to NODE_STEPS steps / LEAF_STEPS leaves while enough of the lanes that started it can go on:
 // it stops when fewer than 1/NODE_KEEP (1/LEAF_KEEP) of them remain. Measured per kernel on Cornell 1080p.
@@ -286,7 +291,7 @@ struct ShadowIO {
 // accesses coalesce) and goes on with an empty one; when the LDS part runs dry it takes the last 8 spilled entries
 // back. Deep trees then need no deeper LDS stacks — the occupancy of a depth-60 scene is that of a depth-14 one — and
 // the order in which nodes are visited, hence every result, is unchanged.
-template <int MODE, bool CULL, int STACK, bool SPILL, class Mem, class IO>
+template <int MODE, bool CULL, int STACK, bool SPILL, int REFILL, class Mem, class IO>
 PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t count, uint32_t gw,
                              uint32_t total_waves, uint32_t *stk, int stride, uint32_t *spill = nullptr,
                              uint32_t spill_lanes = 0) {
@@ -313,7 +318,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
 
     for (;;) {
         uint64_t act = ballot(active);
-        if (next < end && popc(act) <= REFILL_AT) {
+        if (next < end && popc(act) <= REFILL) {
             const uint64_t idle = ~act;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             const uint32_t vi = next + rank;
@@ -479,11 +484,11 @@ __global__ __launch_bounds__(GBLOCK) PT_GLOBAL_ATTR void k_trace_global(DevScene
         QuantMem m{(glb_u4p)sc.qnodes, (glb_u32p)sc.leaf_stream, (glb_f4p)sc.tripos,
                    sc.q_origin[0], sc.q_origin[1], sc.q_origin[2], sc.q_scale[0], sc.q_scale[1], sc.q_scale[2],
                    (lds_u4p)qcache, nc};
-        trace_wave<MODE, CULL, STACK, true>(m, sc, io, count, gw, gridDim.x * (GBLOCK / 64), stk + threadIdx.x, GBLOCK, sp, gridDim.x * GBLOCK);
+        trace_wave<MODE, CULL, STACK, true, PT_REFILL_GLOBAL>(m, sc, io, count, gw, gridDim.x * (GBLOCK / 64), stk + threadIdx.x, GBLOCK, sp, gridDim.x * GBLOCK);
     } else {
         if (gw * 64u >= count) return;
         GlobalMem m{(glb_f4p)sc.wnodes, (glb_f4p)sc.tripos};
-        trace_wave<MODE, CULL, STACK, true>(m, sc, io, count, gw, gridDim.x * (GBLOCK / 64), stk + threadIdx.x, GBLOCK, sp, gridDim.x * GBLOCK);
+        trace_wave<MODE, CULL, STACK, true, PT_REFILL_GLOBAL>(m, sc, io, count, gw, gridDim.x * (GBLOCK / 64), stk + threadIdx.x, GBLOCK, sp, gridDim.x * GBLOCK);
     }
 }
 
@@ -512,7 +517,7 @@ __global__ __launch_bounds__(LBLOCK) void k_trace_lds(DevScene sc, IO io, const 
     if (gw * 64u >= count) return;
     LdsMem<TRIS_IN_LDS> m{(lds_f4p)smem, (lds_f4p)(smem + nw), (glb_f4p)sc.tripos};
     uint32_t *stk = reinterpret_cast<uint32_t *>(smem + nw + nt) + threadIdx.x;
-    trace_wave<MODE, CULL, STACK, SPILL>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk, LBLOCK,
+    trace_wave<MODE, CULL, STACK, SPILL, REFILL_AT>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk, LBLOCK,
                                          SPILL ? spill + (size_t)blockIdx.x * LBLOCK + threadIdx.x : nullptr, gridDim.x * LBLOCK);
 }
 
