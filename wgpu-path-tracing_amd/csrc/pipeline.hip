@@ -109,25 +109,22 @@ __global__ __launch_bounds__(TILE_WORDS) void k_tile_sums(const uint32_t *__rest
     }
 }
 
-__global__ __launch_bounds__(TILE_WORDS) void k_scatter(const uint32_t *__restrict__ count_ptr,
-                                                        const uint32_t *__restrict__ queue,
-                                                        const uint64_t *__restrict__ alive,
-                                                        const uint32_t *__restrict__ tile_sums,
-                                                        uint32_t *__restrict__ next_queue,
-                                                        uint32_t *__restrict__ next_count) {
+PT_DEV void scatter_tile(uint32_t tile, const uint32_t *__restrict__ count_ptr, const uint32_t *__restrict__ queue,
+                         const uint64_t *__restrict__ alive, const uint32_t *__restrict__ tile_sums,
+                         uint32_t *__restrict__ next_queue, uint32_t *__restrict__ next_count) {
     __shared__ uint32_t wtot[TILE_WAVES];
     __shared__ uint32_t tile_base;
     const uint32_t count = *count_ptr;
     const uint32_t nwords = (count + 63u) >> 6;
     const uint32_t ntiles = (nwords + TILE_WORDS - 1) / TILE_WORDS;
-    if (blockIdx.x >= ntiles) {
-        if (ntiles == 0 && blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0;
+    if (tile >= ntiles) {
+        if (ntiles == 0 && tile == 0 && threadIdx.x == 0) *next_count = 0;
         return;
     }
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // totals of the tiles in front of this one
     uint32_t pre = 0;
-    for (uint32_t t = threadIdx.x; t < blockIdx.x; t += TILE_WORDS) pre += tile_sums[t];
+    for (uint32_t t = threadIdx.x; t < tile; t += TILE_WORDS) pre += tile_sums[t];
     for (int off = 32; off > 0; off >>= 1) pre += __shfl_down(pre, off);
     if (lane == 0) wtot[wave] = pre;
     __syncthreads();
@@ -136,7 +133,7 @@ __global__ __launch_bounds__(TILE_WORDS) void k_scatter(const uint32_t *__restri
     const uint32_t base0 = tile_base;
     __syncthreads();
     // exclusive scan of this tile's popcounts
-    const uint32_t w = blockIdx.x * TILE_WORDS + threadIdx.x;
+    const uint32_t w = tile * TILE_WORDS + threadIdx.x;
     const uint64_t m = w < nwords ? alive[w] : 0ull;
     const uint32_t c = (uint32_t)__popcll(m);
     uint32_t inc = c;
@@ -146,10 +143,10 @@ __global__ __launch_bounds__(TILE_WORDS) void k_scatter(const uint32_t *__restri
     uint32_t wbase = 0;
     for (uint32_t i = 0; i < wave; i++) wbase += wtot[i];
     const uint32_t my_off = base0 + wbase + inc - c;                  // offset of this lane's word
-    if (blockIdx.x == ntiles - 1 && threadIdx.x == TILE_WORDS - 1) *next_count = my_off + c;
+    if (tile == ntiles - 1 && threadIdx.x == TILE_WORDS - 1) *next_count = my_off + c;
     // cooperative scatter: the wave walks its 64 words
     const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
-    const uint32_t w0 = blockIdx.x * TILE_WORDS + wave * 64u;
+    const uint32_t w0 = tile * TILE_WORDS + wave * 64u;
     for (uint32_t j = 0; j < 64u; j++) {
         const uint32_t jlo = __shfl(mlo, (int)j), jhi = __shfl(mhi, (int)j), jbase = __shfl(my_off, (int)j);
         const uint64_t jm = ((uint64_t)jhi << 32) | jlo;
@@ -160,6 +157,26 @@ __global__ __launch_bounds__(TILE_WORDS) void k_scatter(const uint32_t *__restri
             next_queue[jbase + below] = queue ? queue[slot] : slot;
         }
     }
+}
+
+__global__ __launch_bounds__(TILE_WORDS) void k_scatter(const uint32_t *__restrict__ count_ptr,
+                                                        const uint32_t *__restrict__ queue,
+                                                        const uint64_t *__restrict__ alive,
+                                                        const uint32_t *__restrict__ tile_sums,
+                                                        uint32_t *__restrict__ next_queue,
+                                                        uint32_t *__restrict__ next_count) {
+    scatter_tile(blockIdx.x, count_ptr, queue, alive, tile_sums, next_queue, next_count);
+}
+// both compactions of a bounce in one launch: workgroups [0, tiles) compact the survivors into the next queue,
+// [tiles, 2 tiles) the emitted records into the shadow index list
+__global__ __launch_bounds__(TILE_WORDS) void k_scatter2(uint32_t tiles, const uint32_t *__restrict__ count_ptr,
+                                                         const uint32_t *__restrict__ queue,
+                                                         const uint64_t *__restrict__ alive, const uint64_t *__restrict__ shadow,
+                                                         const uint32_t *__restrict__ tile_sums, const uint32_t *__restrict__ shadow_sums,
+                                                         uint32_t *__restrict__ next_queue, uint32_t *__restrict__ next_count,
+                                                         uint32_t *__restrict__ shadow_queue, uint32_t *__restrict__ shadow_count) {
+    if (blockIdx.x < tiles) scatter_tile(blockIdx.x, count_ptr, queue, alive, tile_sums, next_queue, next_count);
+    else scatter_tile(blockIdx.x - tiles, count_ptr, nullptr, shadow, shadow_sums, shadow_queue, shadow_count);
 }
 
 // ---- compaction with a local sort by direction octant (ray_sort) -----------------------------------------------------
@@ -364,6 +381,13 @@ void pt_launch_compact(hipStream_t s, int tiles, const uint32_t *queue, const ui
     uint32_t *shadow_sums = tile_sums + tiles;
     hipLaunchKernelGGL(k_tile_sums, dim3(tiles), dim3(TILE_WORDS), 0, s, count, alive_mask, shadow_mask, tile_sums,
                        shadow_sums, stats, bounce);
+#ifndef PT_NO_SCATTER2
+    if (do_scatter && shadow_mask && !octant_masks) {
+        hipLaunchKernelGGL(k_scatter2, dim3(2 * tiles), dim3(TILE_WORDS), 0, s, (uint32_t)tiles, count, queue, alive_mask, shadow_mask,
+                           tile_sums, shadow_sums, next_queue, next_count, shadow_queue, shadow_count);
+        return;
+    }
+#endif
     if (do_scatter && octant_masks)
         hipLaunchKernelGGL(k_scatter_sorted, dim3(tiles), dim3(TILE_WORDS), 0, s, count, queue, alive_mask, octant_masks,
                            octant_stride, tile_sums, next_queue, next_count);

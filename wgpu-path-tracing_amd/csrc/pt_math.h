@@ -17,6 +17,42 @@
 #define PT_EPS 1e-6f              // pt.wgsl:4
 #define PT_DEV __device__ __forceinline__
 
+// Streams that are written once and read once, a kernel later (ray state, hit and shadow records): with PT_NT = 1 they are
+// stored / loaded with the non-temporal hint, so that they do not displace scene data in the L2 (A/B switch; off by default).
+#ifndef PT_NT
+#define PT_NT 0
+#endif
+typedef float pt_f4n __attribute__((ext_vector_type(4)));
+typedef float pt_f2n __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_stream(float4 *p, float4 v) {
+#if PT_NT
+    pt_f4n n = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(n, reinterpret_cast<pt_f4n *>(p));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void st_stream(float2 *p, float2 v) {
+#if PT_NT
+    pt_f2n n = {v.x, v.y}; __builtin_nontemporal_store(n, reinterpret_cast<pt_f2n *>(p));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ float4 ld_stream(const float4 *p) {
+#if PT_NT
+    pt_f4n n = __builtin_nontemporal_load(reinterpret_cast<const pt_f4n *>(p)); return make_float4(n.x, n.y, n.z, n.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ float2 ld_stream(const float2 *p) {
+#if PT_NT
+    pt_f2n n = __builtin_nontemporal_load(reinterpret_cast<const pt_f2n *>(p)); return make_float2(n.x, n.y);
+#else
+    return *p;
+#endif
+}
+
 struct v3 { float x, y, z; };
 struct v4 { float x, y, z, w; };
 

@@ -291,22 +291,22 @@ __global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const
         bool neg_x = false, neg_y = false, neg_z = false;          // ray_sort: octant of the new direction
         if (i < count) {
             const uint32_t p = queue ? queue[i] : i;
-            const float2 h2 = hits[i];
+            const float2 h2 = ld_stream(&hits[i]);
             if (!(h2.x < 0.0f)) {                                            // pt.wgsl:646: miss adds zero
-                const float4 o4 = P.O[p], d4 = P.D[p];
+                const float4 o4 = ld_stream(&P.O[p]), d4 = ld_stream(&P.D[p]);
                 uint32_t rng = __float_as_uint(o4.w);
                 const v3 ro = xyz(o4), rd = xyz(d4);
                 v3 thr = mk3(1.0f, 1.0f, 1.0f);                                      // pt.wgsl:639; raygen stores no throughput
-                if (sp.bounce != 0u) { const float2 c2 = P.C[p]; thr = mk3(d4.w, c2.x, c2.y); }
+                if (sp.bounce != 0u) { const float2 c2 = ld_stream(&P.C[p]); thr = mk3(d4.w, c2.x, c2.y); }
                 const HitInfo hit = make_hitinfo(sc, ro, rd, h2.x, __float_as_uint(h2.y));
                 if (hit.emission.x > 0.0f || hit.emission.y > 0.0f || hit.emission.z > 0.0f) {   // pt.wgsl:652-658
                     float att = 1.0f / (1.0f + hit.t * hit.t);
                     float k = hit.emissive_strength;
                     const v3 e = mk3(thr.x * hit.emission.x * k * att, thr.y * hit.emission.y * k * att, thr.z * hit.emission.z * k * att);
                     if (sp.emit_records) {          // the path ends here: its last addition to L, made by `shadow` in bounce order
-                        S.SO[i] = make_float4(0.0f, 0.0f, 0.0f, -2.0f);
-                        S.SD[i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(p));
-                        S.SC[i] = make_float4(e.x, e.y, e.z, 0.0f);
+                        st_stream(&S.SO[i], make_float4(0.0f, 0.0f, 0.0f, -2.0f));
+                        st_stream(&S.SD[i], make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(p)));
+                        st_stream(&S.SC[i], make_float4(e.x, e.y, e.z, 0.0f));
                         shadow = true; emitted = true;
                     } else {
                         float4 l = P.L[p];
@@ -327,9 +327,9 @@ __global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const
                             // in the statistics like the reference's traversal but neither recorded nor traced.
                             if ((contrib.x != 0.0f) | (contrib.y != 0.0f) | (contrib.z != 0.0f)) {
                                 v3 so = madd3(ls.wi, PT_EPS, hit.position);
-                                S.SO[i] = make_float4(so.x, so.y, so.z, ls.dist);
-                                S.SD[i] = make_float4(ls.wi.x, ls.wi.y, ls.wi.z, __uint_as_float(p));
-                                S.SC[i] = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
+                                st_stream(&S.SO[i], make_float4(so.x, so.y, so.z, ls.dist));
+                                st_stream(&S.SD[i], make_float4(ls.wi.x, ls.wi.y, ls.wi.z, __uint_as_float(p)));
+                                st_stream(&S.SC[i], make_float4(contrib.x, contrib.y, contrib.z, 0.0f));
                                 shadow = true;
                             } else {
                                 skipped = true;
@@ -352,9 +352,9 @@ __global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const
                         }
                         if (alive && sp.bounce + 1u < sp.max_bounces) {
                             neg_x = nd.x < 0.0f; neg_y = nd.y < 0.0f; neg_z = nd.z < 0.0f;
-                            P.O[p] = make_float4(no.x, no.y, no.z, __uint_as_float(rng));
-                            P.D[p] = make_float4(nd.x, nd.y, nd.z, thr.x);
-                            P.C[p] = make_float2(thr.y, thr.z);
+                            st_stream(&P.O[p], make_float4(no.x, no.y, no.z, __uint_as_float(rng)));
+                            st_stream(&P.D[p], make_float4(nd.x, nd.y, nd.z, thr.x));
+                            st_stream(&P.C[p], make_float2(thr.y, thr.z));
                         }
                     }
                 }

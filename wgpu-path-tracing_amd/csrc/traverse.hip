@@ -39,9 +39,9 @@ constexpr int MODE_EXTEND = 0, MODE_SHADOW = 1;
 #endif
 constexpr int REFILL_AT = PT_REFILL_AT;   // refill when at most this many of the 64 lanes still hold a ray (scene in LDS)
 // The kernels that walk the scene from global memory refill earlier: a lane without a ray also means a memory request
-// less in flight. Measured on the 1 M-triangle scene (Msamples/s): 28: 4 404, 36: 4 543, 44: 4 638; Cornell ±1 % throughout.
+// less in flight. Measured on the 1 M-triangle scene (Msamples/s): 28: 4 404, 36: 4 543, 44: 4 636, 52: 4 667, 58: 4 651; Cornell ±1 % throughout.
 #ifndef PT_REFILL_GLOBAL
-#define PT_REFILL_GLOBAL 44
+#define PT_REFILL_GLOBAL 52
 #endif
 // One vote (two ballots, the refill and completion tests) costs about half a box-pair step, so a stream keeps
 // running for up to NODE_STEPS steps / LEAF_STEPS leaves while enough of the lanes that started it can go on:
@@ -246,7 +246,7 @@ struct ExtendIO {
         o = xyz(o4); d = xyz(d4); tlim = 0.0f;
         return true;
     }
-    PT_DEV void finish(uint32_t slot, const Hit &h, bool) const { hits[slot] = pack_hit(h); }
+    PT_DEV void finish(uint32_t slot, const Hit &h, bool) const { st_stream(&hits[slot], pack_hit(h)); }
 };
 struct ShadowIO {
     DevPaths P; DevShadow S; const uint32_t *sq; uint8_t *occluded_out;
@@ -254,7 +254,7 @@ struct ShadowIO {
     PT_DEV bool fetch(uint32_t &slot, v3 &o, v3 &d, float &tlim) const {
         uint32_t i = sq ? sq[slot] : slot;
         slot = i;                                              // the record's own slot is what finish() needs
-        float4 so = S.SO[i], sd = S.SD[i];
+        float4 so = ld_stream(&S.SO[i]), sd = ld_stream(&S.SD[i]);
         o = xyz(so); d = xyz(sd);
         // pt.wgsl:423, :465: occluded iff a hit is nearer than dist - 2e-6 (negative for a light closer than 2e-6: never
         // occluded). A directional light (:394) has no distance, any hit occludes, one at t = +inf included: tlim = NaN,
@@ -266,7 +266,7 @@ struct ShadowIO {
         if (occluded_out) { occluded_out[i] = occluded ? 1 : 0; return; }
         if (!occluded) {
             uint32_t p = __float_as_uint(S.SD[i].w);
-            float4 l = P.L[p], c = S.SC[i];
+            float4 l = P.L[p], c = ld_stream(&S.SC[i]);
             P.L[p] = make_float4(l.x + c.x, l.y + c.y, l.z + c.z, 0.0f);   // pt.wgsl:675
         }
     }
