@@ -157,7 +157,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--perf-mode", type=int, default=0, help="library option perf_mode (0 = parity arithmetic, the headline)")
     ap.add_argument("--sort", type=int, default=None, help="library option ray_sort (default: the library's)")
-    ap.add_argument("--overlap", type=int, default=None, help="library option overlap (0: one stream; default: the library's)")
+    ap.add_argument("--overlap", type=int, default=None,
+                    help="library option overlap (0: one stream; 1: shadow kernel on a second stream; 3: also two half-batches in "
+                         "flight; default: the library's)")
     ap.add_argument("--keep-reference-tree", action="store_true",
                     help="walk the BVH exactly as uploaded instead of the hierarchy rebuilt over its leaves")
     ap.add_argument("--rehearse", action="store_true",

@@ -77,7 +77,10 @@ typedef struct ptmi_options {
     uint32_t overlap;           /* 0: every kernel of a dispatch on the context's one stream, in order; 1: the any-hit `shadow` kernel of
                                    bounce b runs on a second (lower-priority) stream beside `extend` / `shade` of bounce b + 1 — it is
                                    the only kernel that adds to the radiance then, in bounce order, so results are unchanged;
-                                   2 = library default (currently 1 when next-event estimation is on) */
+                                   3: additionally each batch is traced as two halves on two lanes (own buffers and streams), the
+                                   second started when the first has finished bounce 3, so that a half's last bounces run beside
+                                   the next half's first ones; the halves are folded into the output in frame order on the
+                                   context's stream. 2 = library default (currently 3) */
     uint32_t reserved[1];
 } ptmi_options;
 

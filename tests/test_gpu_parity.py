@@ -282,9 +282,10 @@ def test_ray_sort_is_invisible(gpu_ctx, oracle, scene_factory, name):
 
 @pytest.mark.parametrize("name,trav", [("cornell", 0), ("feature_box", 0), ("cornell_spheres", 1)])
 def test_overlapped_shadow_stream_is_invisible(gpu_ctx, oracle, scene_factory, name, trav):
-    """options.overlap: with it the shadow kernel of bounce b runs on a second stream beside the next bounce, emissive hits
-    reach the radiance through records, and the record buffers alternate; without it everything is on one stream and
-    `shade` adds emission itself. Both must give the oracle's bits and counters — also over several batches in one
+    """options.overlap: with 1 the shadow kernel of bounce b runs on a second stream beside the next bounce, emissive hits
+    reach the radiance through records, and the record buffers alternate; with 3 every batch is additionally traced as two
+    halves on two lanes, staggered by four bounces and folded in frame order; without it everything is on one stream and
+    `shade` adds emission itself. All must give the oracle's bits and counters — also over several batches in one
     dispatch (frames_per_batch 2 of 5 frames: the buffers and events are reused), 1 and 2 bounces (fewer bounces than
     buffers) and with the global traversal variant (its own spill area on the side stream)."""
     sc = scene_factory(name)
@@ -293,7 +294,7 @@ def test_overlapped_shadow_stream_is_invisible(gpu_ctx, oracle, scene_factory, n
     gpu_ctx.upload_scene(sc)
     for bounces in (8, 2, 1):
         ref, ost = oracle.render(sc, cam, frames, max_bounces=bounces, do_mis=1)
-        for overlap, fpb in ((1, 0), (1, 2), (0, 0)):
+        for overlap, fpb in ((3, 0), (3, 2), (3, 5), (1, 0), (1, 2), (0, 0)):      # 3: two half-batches in flight on two lanes
             gpu_ctx.resize(W, H)
             gpu_ctx.set_options(max_bounces=bounces, do_mis=1, tile_y0=0, tile_y1=0, tile_parts=0, frames_per_batch=fpb, cull=1,
                                 traversal=trav, overlap=overlap, timing=3)
@@ -304,6 +305,29 @@ def test_overlapped_shadow_stream_is_invisible(gpu_ctx, oracle, scene_factory, n
             assert (st.segments, st.shadow_rays, st.paths) == (ost.segments, ost.shadow_rays, ost.paths)
             assert_same_floats(got, ref, f"radiance ({name}, overlap {overlap}, frames_per_batch {fpb}, {bounces} bounces)")
     gpu_ctx.set_options(overlap=2, frames_per_batch=0, traversal=0, max_bounces=8, timing=0)
+
+
+def test_two_lanes_across_dispatches(gpu_ctx, oracle, scene_factory):
+    """Consecutive dispatches without a synchronisation in between (the preview loop, the benchmark's steps): with two
+    lanes the second dispatch starts while the first one's last bounces still run, and a lane is reused as soon as its
+    half has been folded. Six dispatches of 4, 1, 3, 2, 6, 1 frames (one-frame dispatches use a single lane: the library
+    drains when the lane layout changes) must leave the oracle's 17 frames."""
+    sc = scene_factory("cornell")
+    W, H = 128, 96
+    ref, ost = oracle.render(sc, layout.make_camera(W, H), 17, max_bounces=8, do_mis=1)
+    gpu_ctx.upload_scene(sc)
+    gpu_ctx.resize(W, H)
+    gpu_ctx.set_options(max_bounces=8, do_mis=1, tile_y0=0, tile_y1=0, tile_parts=0, frames_per_batch=0, cull=1, traversal=0, overlap=3)
+    gpu_ctx.reset_stats()
+    k = 0
+    for n in (4, 1, 3, 2, 6, 1):
+        gpu_ctx.dispatch(layout.make_camera(W, H, frame_index=k), n)
+        k += n
+    got = gpu_ctx.read_output()
+    st = gpu_ctx.stats()
+    assert (st.segments, st.shadow_rays, st.paths) == (ost.segments, ost.shadow_rays, ost.paths)
+    assert_same_floats(got, ref, "radiance after six pipelined dispatches")
+    gpu_ctx.set_options(overlap=2)
 
 
 def test_errors_are_loud(gpu_ctx, scene_factory):

@@ -92,7 +92,9 @@ __global__ __launch_bounds__(TILE_WORDS) void k_tile_sums(const uint32_t *__rest
     __shared__ uint32_t wsum[TILE_WAVES], wssum[TILE_WAVES];
     const uint32_t count = *count_ptr;
     const uint32_t nwords = (count + 63u) >> 6;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { stats[0] += count; stats[8 + bounce] += count; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {          // atomics: two batches may be in flight on two lanes
+        atomicAdd(&stats[0], (unsigned long long)count); atomicAdd(&stats[8 + bounce], (unsigned long long)count);
+    }
     if (blockIdx.x * TILE_WORDS >= nwords) return;
     const uint32_t w = blockIdx.x * TILE_WORDS + threadIdx.x;
     uint32_t c = 0, sc = 0;

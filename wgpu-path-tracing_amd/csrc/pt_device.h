@@ -85,6 +85,7 @@ struct TraverseConfig {
     size_t lds_scene_bytes; // LDS variant: bytes of wnodes + tripos
     int wgs_per_cu;         // node cache: 2 (small trees, whole stack in LDS) or 1 (mid-size trees, spilling stacks)
     uint32_t *spill;        // global variant: per-lane overflow of the node stack, pt_spill_bytes(blocks) bytes
+    int wants_spill;        // the variant needs one (the caller supplies `spill`: each concurrently running kernel its own)
     int quantized;          // global variant: walk the quantised image when the scene has one
 };
 #ifndef PT_QCACHE_NODES

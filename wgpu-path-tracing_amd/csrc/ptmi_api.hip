@@ -26,11 +26,34 @@ constexpr size_t kMaxPendingEvents = 4096;        // a caller that never synchro
 
 }  // namespace
 
+// One wavefront batch in flight: its buffers, and (options.overlap) the streams and events that let it run beside another.
+struct Lane {
+    size_t cap = 0;
+    DevPaths paths{};
+    float2 *hits = nullptr;
+    DevShadow sh[2]{};                                 // shadow records, double-buffered by bounce parity (overlap >= 1)
+    uint32_t *queue[2] = {nullptr, nullptr}, *sq[2] = {nullptr, nullptr};
+    uint64_t *alive = nullptr, *shadowm = nullptr, *octm = nullptr;   // octm: 3 x words (ray_sort)
+    size_t mask_words = 0;
+    uint32_t *word_off = nullptr, *counts = nullptr;
+    uint32_t *d_spill = nullptr;          // node-stack overflow of the global traversal variant (128 MiB on 256 CUs; first use)
+    uint32_t *d_spill_side = nullptr;     // ... of the `shadow` kernel when it runs beside `extend`
+    uint8_t *d_occ = nullptr;
+    hipStream_t main = nullptr;           // overlap 3: this lane's own stream (else the context's stream is used)
+    hipStream_t side = nullptr;           // `shadow` of bounce b beside the kernels of bounce b + 1
+    hipEvent_t ev_ready = nullptr, ev_shadow[2] = {nullptr, nullptr};
+    hipEvent_t ev_mid = nullptr;          // recorded after the compaction of bounce 3: the other lane's next batch may start
+    hipEvent_t ev_done = nullptr;         // all kernels of the batch finished (accumulate, on the context's stream, waits for it)
+    hipEvent_t ev_free = nullptr;         // its accumulate finished: the buffers may be overwritten
+    bool mid_recorded = false, free_recorded = false;
+};
+
 struct ptmi_ctx {
     int device = 0, n_cu = 256;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    hipStream_t side_stream = nullptr;                 // `shadow` of bounce b beside the kernels of bounce b + 1 (options.overlap)
-    hipEvent_t ev_ready = nullptr, ev_shadow[2] = {nullptr, nullptr};
+    Lane lanes[2];
+    uint64_t batch_seq = 0;                            // batches launched so far (two lanes: batch k runs on lane k & 1)
+    bool last_two_lanes = false;                       // how the previous dispatch used the lanes
     mutable std::string err;
     ptmi_options opt{};
 
@@ -47,19 +70,7 @@ struct ptmi_ctx {
     uint32_t W = 0, H = 0;
     float4 *d_out_own = nullptr, *d_out = nullptr;
 
-    // wavefront batch buffers
-    size_t cap = 0;
-    DevPaths paths{};
-    float2 *hits = nullptr;
-    DevShadow sh[2]{};                                 // shadow records, double-buffered by bounce parity (overlap)
-    uint32_t *queue[2] = {nullptr, nullptr}, *sq[2] = {nullptr, nullptr};
-    uint64_t *alive = nullptr, *shadowm = nullptr, *octm = nullptr;   // octm: 3 x words (ray_sort)
-    size_t mask_words = 0;
-    uint32_t *word_off = nullptr, *counts = nullptr;
     unsigned long long *d_stats = nullptr;
-    uint32_t *d_spill = nullptr;          // node-stack overflow of the global traversal variant (128 MiB on 256 CUs, allocated by ptmi_create)
-    uint32_t *d_spill_side = nullptr;     // ... of the `shadow` kernel when it runs beside `extend` (allocated on first use)
-    uint8_t *d_occ = nullptr;
     float4 *d_blit_f32 = nullptr; uint32_t *d_blit_u8 = nullptr; size_t blit_px = 0;   // canvas staging of ptmi_blit, kept between calls
 
     // statistics
@@ -140,35 +151,45 @@ struct Timed {
     }
 };
 
-void free_batch(ptmi_ctx *c) {
-    dfree(c->paths.O); dfree(c->paths.D); dfree(c->paths.C); dfree(c->paths.L);
-    dfree(c->hits);
-    for (int k = 0; k < 2; k++) { dfree(c->sh[k].SO); dfree(c->sh[k].SD); dfree(c->sh[k].SC); dfree(c->sq[k]); }
-    dfree(c->queue[0]); dfree(c->queue[1]); dfree(c->alive); dfree(c->shadowm); dfree(c->octm); dfree(c->word_off); dfree(c->d_occ);
-    c->cap = 0;
+void free_batch(Lane &ln) {
+    dfree(ln.paths.O); dfree(ln.paths.D); dfree(ln.paths.C); dfree(ln.paths.L);
+    dfree(ln.hits);
+    for (int k = 0; k < 2; k++) { dfree(ln.sh[k].SO); dfree(ln.sh[k].SD); dfree(ln.sh[k].SC); dfree(ln.sq[k]); }
+    dfree(ln.queue[0]); dfree(ln.queue[1]); dfree(ln.alive); dfree(ln.shadowm); dfree(ln.octm); dfree(ln.word_off); dfree(ln.d_occ);
+    ln.cap = 0;
 }
 
-int ensure_capacity(ptmi_ctx *c, size_t n) {
-    if (n <= c->cap) return PTMI_OK;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->side_stream) HIP_TRY(c, hipStreamSynchronize(c->side_stream));
-    free_batch(c);
+// everything the library has in flight, on every stream it owns
+hipError_t sync_all(ptmi_ctx *c) {
+    hipError_t e = c->stream ? hipStreamSynchronize(c->stream) : hipSuccess;
+    for (Lane &ln : c->lanes) {
+        if (e == hipSuccess && ln.main) e = hipStreamSynchronize(ln.main);
+        if (e == hipSuccess && ln.side) e = hipStreamSynchronize(ln.side);
+    }
+    if (e == hipSuccess && c->stream) e = hipStreamSynchronize(c->stream);      // accumulates that waited for a lane
+    return e;
+}
+
+int ensure_capacity(ptmi_ctx *c, Lane &ln, size_t n) {
+    if (n <= ln.cap) return PTMI_OK;
+    HIP_TRY(c, sync_all(c));
+    free_batch(ln);
     size_t cap = (n + 1023) & ~(size_t)1023;
     size_t words = cap / 64 + 1;
     size_t tiles = cap / pt_compact_tile_slots() + 2;
-    HIP_TRY(c, hipMalloc(&c->paths.O, cap * 16)); HIP_TRY(c, hipMalloc(&c->paths.D, cap * 16));
-    HIP_TRY(c, hipMalloc(&c->paths.C, cap * 8)); HIP_TRY(c, hipMalloc(&c->paths.L, cap * 16));
-    HIP_TRY(c, hipMalloc(&c->hits, cap * 8));
+    HIP_TRY(c, hipMalloc(&ln.paths.O, cap * 16)); HIP_TRY(c, hipMalloc(&ln.paths.D, cap * 16));
+    HIP_TRY(c, hipMalloc(&ln.paths.C, cap * 8)); HIP_TRY(c, hipMalloc(&ln.paths.L, cap * 16));
+    HIP_TRY(c, hipMalloc(&ln.hits, cap * 8));
     for (int k = 0; k < 2; k++) {
-        HIP_TRY(c, hipMalloc(&c->sh[k].SO, cap * 16)); HIP_TRY(c, hipMalloc(&c->sh[k].SD, cap * 16));
-        HIP_TRY(c, hipMalloc(&c->sh[k].SC, cap * 16)); HIP_TRY(c, hipMalloc(&c->sq[k], cap * 4));
+        HIP_TRY(c, hipMalloc(&ln.sh[k].SO, cap * 16)); HIP_TRY(c, hipMalloc(&ln.sh[k].SD, cap * 16));
+        HIP_TRY(c, hipMalloc(&ln.sh[k].SC, cap * 16)); HIP_TRY(c, hipMalloc(&ln.sq[k], cap * 4));
     }
-    HIP_TRY(c, hipMalloc(&c->queue[0], cap * 4)); HIP_TRY(c, hipMalloc(&c->queue[1], cap * 4));
-    HIP_TRY(c, hipMalloc(&c->alive, words * 8)); HIP_TRY(c, hipMalloc(&c->shadowm, words * 8));
-    HIP_TRY(c, hipMalloc(&c->octm, 3 * words * 8)); c->mask_words = words;
-    HIP_TRY(c, hipMalloc(&c->word_off, 2 * tiles * 4));
-    HIP_TRY(c, hipMalloc(&c->d_occ, cap));
-    c->cap = cap;
+    HIP_TRY(c, hipMalloc(&ln.queue[0], cap * 4)); HIP_TRY(c, hipMalloc(&ln.queue[1], cap * 4));
+    HIP_TRY(c, hipMalloc(&ln.alive, words * 8)); HIP_TRY(c, hipMalloc(&ln.shadowm, words * 8));
+    HIP_TRY(c, hipMalloc(&ln.octm, 3 * words * 8)); ln.mask_words = words;
+    HIP_TRY(c, hipMalloc(&ln.word_off, 2 * tiles * 4));
+    HIP_TRY(c, hipMalloc(&ln.d_occ, cap));
+    ln.cap = cap;
     return PTMI_OK;
 }
 
@@ -305,7 +326,7 @@ TraverseConfig traverse_config(const ptmi_ctx *c, bool closest_hit) {
     const int small_stack = c->bvh_depth + 1 <= 15 ? 15 : 16;  // node stack <= depth - 2, plus >= 3 entries for filed leaves
     const bool node_cache = have && c->bvh_depth + 2 <= 16 &&
                             (size_t)c->sc.n_wnodes * 64 + (size_t)small_stack * 1024 * 4 <= kLdsMax / 2;
-    cfg.spill = nullptr; cfg.wgs_per_cu = 2;
+    cfg.spill = nullptr; cfg.wants_spill = 0; cfg.wgs_per_cu = 2;
     // The quantised image pays where node fetches leave the L2 (measured: the 1 M-triangle scene, 67 MB, extend -16 %); a scene
     // that an XCD's 4 MiB L2 holds is bound by the ALUs, and decoding costs more than the bytes save (cornell_spheres walked
     // from global memory: shadow +30 %). AUTO decides by size; GLOBAL asks for the quantised image, GLOBAL_EXACT for the exact one.
@@ -319,10 +340,10 @@ TraverseConfig traverse_config(const ptmi_ctx *c, bool closest_hit) {
              (size_t)c->sc.n_wnodes * 64 + (size_t)16 * 1024 * 4 <= kLdsMax) {
         // mid-size trees (up to 1536 wide nodes): all nodes in LDS, one workgroup per CU, stacks spill. Measured on
         // cornell_spheres against the global variant: extend -6 %, shadow +5 % (so closest hit only)
-        cfg.variant = PT_VARIANT_LDS_NODES; cfg.wgs_per_cu = 1; cfg.stack_entries = 16; cfg.spill = c->d_spill;
+        cfg.variant = PT_VARIANT_LDS_NODES; cfg.wgs_per_cu = 1; cfg.stack_entries = 16; cfg.wants_spill = 1;
     }
     else cfg.variant = PT_VARIANT_GLOBAL;
-    if (cfg.variant == PT_VARIANT_GLOBAL) { cfg.stack_entries = 16; cfg.spill = c->d_spill; }   // deeper stacks spill
+    if (cfg.variant == PT_VARIANT_GLOBAL) { cfg.stack_entries = 16; cfg.wants_spill = 1; }   // deeper stacks spill
     return cfg;
 }
 
@@ -341,7 +362,7 @@ int upload_rays(ptmi_ctx *c, uint32_t n, const float *o3, const float *d3, const
     }
     HIP_TRY(c, hipMemcpyAsync(dO, o.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(dD, d.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     return PTMI_OK;
 }
 
@@ -378,19 +399,20 @@ int ptmi_create(int device_ordinal, ptmi_ctx **out) {
     }
     c->stream = c->own_stream;
     {
-        int lo = 0, hi = 0;                                  // the side stream yields to the main one
+        int lo = 0, hi = 0;                                  // the side streams yield to the main ones
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, lo) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev_shadow[0], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev_shadow[1], hipEventDisableTiming) != hipSuccess) {
-            ptmi_destroy(c); return fail(nullptr, PTMI_E_HIP, "side stream / event creation failed");
+        bool ok = true;
+        for (Lane &ln : c->lanes) {
+            ok = ok && hipStreamCreateWithFlags(&ln.main, hipStreamNonBlocking) == hipSuccess;
+            ok = ok && hipStreamCreateWithPriority(&ln.side, hipStreamNonBlocking, lo) == hipSuccess;
+            for (hipEvent_t *e : {&ln.ev_ready, &ln.ev_shadow[0], &ln.ev_shadow[1], &ln.ev_mid, &ln.ev_done, &ln.ev_free})
+                ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipMalloc(&ln.counts, 80 * sizeof(uint32_t)) == hipSuccess;
         }
+        if (!ok) { ptmi_destroy(c); return fail(nullptr, PTMI_E_HIP, "stream / event creation failed"); }
     }
-    if (hipMalloc(&c->counts, 80 * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(&c->d_stats, kStatsWords * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(c->d_stats, 0, kStatsWords * sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc(&c->d_spill, pt_spill_bytes(c->n_cu * 8)) != hipSuccess) {                 // 128 MiB on 256 CUs
+    if (hipMalloc(&c->d_stats, kStatsWords * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c->d_stats, 0, kStatsWords * sizeof(unsigned long long)) != hipSuccess) {
         ptmi_destroy(c); return fail(nullptr, PTMI_E_HIP, "device allocation failed");
     }
     *out = c;
@@ -400,18 +422,19 @@ int ptmi_create(int device_ordinal, ptmi_ctx **out) {
 int ptmi_destroy(ptmi_ctx *c) {
     if (!c) return PTMI_E_INVALID;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
+    (void)sync_all(c);
     drain_events(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-    free_batch(c);
+    for (Lane &ln : c->lanes) {
+        free_batch(ln);
+        dfree(ln.counts); dfree(ln.d_spill); dfree(ln.d_spill_side);
+        for (hipEvent_t e : {ln.ev_ready, ln.ev_shadow[0], ln.ev_shadow[1], ln.ev_mid, ln.ev_done, ln.ev_free}) if (e) (void)hipEventDestroy(e);
+        if (ln.side) (void)hipStreamDestroy(ln.side);
+        if (ln.main) (void)hipStreamDestroy(ln.main);
+    }
     dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_atlas); dfree(c->d_wnodes); dfree(c->d_tripos);
     dfree(c->d_fast_wnodes); dfree(c->d_qnodes); dfree(c->d_leaf_stream);
-    dfree(c->d_out_own); dfree(c->counts); dfree(c->d_stats); dfree(c->d_spill); dfree(c->d_blit_f32); dfree(c->d_blit_u8);
-    dfree(c->d_spill_side);
-    if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
-    for (hipEvent_t e : c->ev_shadow) if (e) (void)hipEventDestroy(e);
-    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    dfree(c->d_out_own); dfree(c->d_stats); dfree(c->d_blit_f32); dfree(c->d_blit_u8);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return PTMI_OK;
@@ -460,7 +483,7 @@ int ptmi_upload_scene(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const
         dfree(n_tris); dfree(n_mats); dfree(n_lights); dfree(n_wnodes); dfree(n_tripos); dfree(n_fast); dfree(n_qnodes); dfree(n_stream);
         return fail(c, PTMI_E_HIP, "scene upload failed: %s (the previous scene, if any, is still in place)", hipGetErrorString(e));
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));                  // nothing in flight reads the old buffers any more
+    HIP_TRY(c, sync_all(c));                  // nothing in flight reads the old buffers any more
     dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_wnodes); dfree(c->d_tripos); dfree(c->d_fast_wnodes);
     dfree(c->d_qnodes); dfree(c->d_leaf_stream);
     c->d_qnodes = n_qnodes; c->d_leaf_stream = n_stream;
@@ -492,7 +515,7 @@ int ptmi_upload_scene(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const
 int ptmi_upload_atlas(ptmi_ctx *c, const void *texels, uint32_t w, uint32_t h, int fmt) {
     if (!c) return PTMI_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     dfree(c->d_atlas);
     c->sc.atlas = nullptr; c->sc.atlas_w = c->sc.atlas_h = c->sc.atlas_fmt = 0;
     if (!texels || w == 0 || h == 0) return PTMI_OK;
@@ -508,7 +531,7 @@ int ptmi_resize(ptmi_ctx *c, uint32_t w, uint32_t h) {
     if (!c) return PTMI_E_INVALID;
     if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 28)) return fail(c, PTMI_E_INVALID, "bad size %ux%u", w, h);
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     dfree(c->d_out_own);
     size_t bytes = (size_t)w * h * PTMI_OUTPUT_STRIDE;
     HIP_TRY(c, hipMalloc(&c->d_out_own, bytes));
@@ -526,7 +549,7 @@ int ptmi_set_options(ptmi_ctx *c, const ptmi_options *o) {
         return fail(c, PTMI_E_INVALID, "tile_part %u is not below tile_parts %u", o->tile_part, o->tile_parts);
     if (o->perf_mode > 1) return fail(c, PTMI_E_INVALID, "unknown perf_mode %u", o->perf_mode);
     if (o->ray_sort > 2) return fail(c, PTMI_E_INVALID, "unknown ray_sort %u", o->ray_sort);
-    if (o->overlap > 2) return fail(c, PTMI_E_INVALID, "unknown overlap %u", o->overlap);
+    if (o->overlap > 3) return fail(c, PTMI_E_INVALID, "unknown overlap %u", o->overlap);
     c->opt = *o;
     return PTMI_OK;
 }
@@ -558,70 +581,98 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     uint32_t F = c->opt.frames_per_batch;
     if (F == 0) { F = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, (64ull << 20) / npix)); }   // ~64 Mi paths, ~10 GB of state
     F = std::min(F, n_frames);
-    if (npix * F > 0xFFFFFF00ull) return fail(c, PTMI_E_UNSUPPORTED, "batch of %llu paths exceeds 2^32", (unsigned long long)(npix * F));
-    rc = ensure_capacity(c, (size_t)(npix * F));
-    if (rc) return rc;
-    const TraverseConfig cfg = traverse_config(c, true), cfg_shadow = traverse_config(c, false);
-    if (c->opt.traversal == PTMI_TRAVERSAL_LDS && cfg.variant != PT_VARIANT_LDS)
+    const bool nee = c->opt.do_mis && c->sc.n_lights > 0;
+    // overlap 1: `shadow` of bounce b on a side stream, beside extend / shade of bounce b + 1. It is then the only kernel that
+    // adds to L (emissive hits leave a record too, ShadeParams::emit_records), bounce after bounce on one stream, so every
+    // path's sum is formed in the same order as without it. Record buffers alternate by bounce parity; shade(b) waits for
+    // shadow(b - 2), the end of the batch for the last one.
+    // overlap 3 (the default, 2): additionally every batch is traced as two halves on two lanes (own buffers, own streams), the
+    // second half started when the first has compacted bounce 3 — the first half's last bounces (a tenth of the rays in queues
+    // too small for the machine) then run beside the second half's first ones, and the second half's beside the next
+    // dispatch's. `accumulate` stays on the context's stream, in frame order, after its lane's kernels.
+    const bool side = nee && c->opt.overlap != 0;
+    const bool two_lanes = c->opt.overlap >= 2 && F >= 2;
+    const uint32_t Fsub = two_lanes ? (F + 1) / 2 : F;              // frames per traced batch
+    if (npix * Fsub > 0xFFFFFF00ull) return fail(c, PTMI_E_UNSUPPORTED, "batch of %llu paths exceeds 2^32", (unsigned long long)(npix * Fsub));
+    const TraverseConfig cfg0 = traverse_config(c, true), cfg_shadow0 = traverse_config(c, false);
+    if (c->opt.traversal == PTMI_TRAVERSAL_LDS && cfg0.variant != PT_VARIANT_LDS)
         return fail(c, PTMI_E_UNSUPPORTED, "scene needs %zu B of LDS plus the stack; it does not fit in %zu B", c->lds_scene_bytes, kLdsMax);
-    c->st.traversal_used = cfg.variant == PT_VARIANT_GLOBAL ? PTMI_TRAVERSAL_GLOBAL : PTMI_TRAVERSAL_LDS;
-    c->st.frames_per_batch_used = F;
+    if (two_lanes != c->last_two_lanes) { HIP_TRY(c, sync_all(c)); c->last_two_lanes = two_lanes; }     // lane 0 changes streams
+    for (int k = 0; k < (two_lanes ? 2 : 1); k++) {
+        Lane &ln = c->lanes[k];
+        rc = ensure_capacity(c, ln, (size_t)(npix * Fsub));
+        if (rc) return rc;
+        if (cfg0.wants_spill && !ln.d_spill) HIP_TRY(c, hipMalloc(&ln.d_spill, pt_spill_bytes(c->n_cu * 8)));          // 128 MiB on 256 CUs
+        if (cfg_shadow0.wants_spill && !ln.d_spill_side) HIP_TRY(c, hipMalloc(&ln.d_spill_side, pt_spill_bytes(c->n_cu * 8)));
+    }
+    c->st.traversal_used = cfg0.variant == PT_VARIANT_GLOBAL ? PTMI_TRAVERSAL_GLOBAL : PTMI_TRAVERSAL_LDS;
+    c->st.frames_per_batch_used = Fsub;
     const int blocks = c->n_cu * 8;
-    const int tiles = (int)(c->cap / pt_compact_tile_slots() + 1);
     const uint32_t maxb = c->opt.max_bounces;
     const bool sort = c->opt.ray_sort == 1;          // 2 (library default) = off: measured, profiles/README.md
     const bool t1 = c->opt.timing >= 1, t2 = c->opt.timing >= 2, t3 = c->opt.timing >= 3;
-    const bool nee = c->opt.do_mis && c->sc.n_lights > 0;
-    // overlap: `shadow` of bounce b on the side stream, beside extend / shade of bounce b + 1. It is then the only kernel that
-    // adds to L (emissive hits leave a record too, ShadeParams::emit_records), bounce after bounce on one stream, so every
-    // path's sum is formed in the same order as without it. Record buffers alternate by bounce parity; shade(b) waits for
-    // shadow(b - 2), accumulate for the last one.
-    const bool overlap = nee && c->opt.overlap != 0;
-    TraverseConfig cfg_side = cfg_shadow;
-    if (overlap && cfg_shadow.variant == PT_VARIANT_GLOBAL) {           // its own spill area: it runs beside `extend`
-        if (!c->d_spill_side) HIP_TRY(c, hipMalloc(&c->d_spill_side, pt_spill_bytes(c->n_cu * 8)));
-        cfg_side.spill = c->d_spill_side;
-    }
     {
         Timed td(c, 0, t1);
-        for (uint32_t f0 = 0; f0 < n_frames; f0 += F) {
-            const uint32_t fb = std::min(F, n_frames - f0);
+        for (uint32_t f0 = 0; f0 < n_frames; f0 += Fsub) {
+            const uint32_t fb = std::min(Fsub, n_frames - f0);
             const uint32_t frame0 = cam->frame_index + f0;
-            { Timed t(c, 4, t3); pt_launch_raygen(c->stream, blocks, *cam, band, frame0, fb, c->paths, &c->counts[0]); }
+            Lane &ln = c->lanes[two_lanes ? (c->batch_seq & 1u) : 0];
+            Lane &other = c->lanes[two_lanes ? ((c->batch_seq & 1u) ^ 1u) : 0];
+            c->batch_seq++;
+            const hipStream_t ms = two_lanes ? ln.main : c->stream;                   // where this batch's kernels go
+            const hipStream_t ss = side ? ln.side : ms;                               // ... and its shadow kernels
+            const int tiles = (int)(ln.cap / pt_compact_tile_slots() + 1);
+            TraverseConfig cfg = cfg0, cfg_shadow = cfg_shadow0;
+            cfg.spill = ln.d_spill; cfg_shadow.spill = side ? ln.d_spill_side : ln.d_spill;
+            if (cfg_shadow.wants_spill && !cfg_shadow.spill) cfg_shadow.spill = ln.d_spill_side;
+            if (two_lanes) {
+                if (ln.free_recorded) HIP_TRY(c, hipStreamWaitEvent(ms, ln.ev_free, 0));            // its buffers were folded
+                if (other.mid_recorded) HIP_TRY(c, hipStreamWaitEvent(ms, other.ev_mid, 0));        // the stagger
+            }
+            { Timed t(c, 4, t3, ms); pt_launch_raygen(ms, blocks, *cam, band, frame0, fb, ln.paths, &ln.counts[0]); }
             int cur = 0;
+            const uint32_t mid_bounce = std::min(3u, maxb - 1u);
             for (uint32_t b = 0; b < maxb; b++) {
-                const uint32_t *q = b == 0 ? nullptr : c->queue[cur];      // bounce 0: slot i holds path i
-                const int par = overlap ? (int)(b & 1u) : 0;
-                { Timed t(c, 1, t2); pt_launch_extend(c->stream, blocks, cfg, c->sc, c->paths, q, &c->counts[b], c->hits); }
+                const uint32_t *q = b == 0 ? nullptr : ln.queue[cur];      // bounce 0: slot i holds path i
+                const int par = side ? (int)(b & 1u) : 0;
+                { Timed t(c, 1, t2, ms); pt_launch_extend(ms, blocks, cfg, c->sc, ln.paths, q, &ln.counts[b], ln.hits); }
                 const bool last = b + 1 == maxb;
-                uint64_t *octm = (sort && !last) ? c->octm : nullptr;
-                if (overlap && b >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_shadow[par], 0));      // its records are read
-                { Timed t(c, 2, t3);
+                uint64_t *octm = (sort && !last) ? ln.octm : nullptr;
+                if (side && b >= 2) HIP_TRY(c, hipStreamWaitEvent(ms, ln.ev_shadow[par], 0));      // its records are read
+                { Timed t(c, 2, t3, ms);
                   (c->opt.perf_mode ? pt_launch_shade_fast : pt_launch_shade)(
-                      c->stream, blocks, c->sc, c->paths, q, &c->counts[b], c->hits, c->sh[par], c->alive, c->shadowm,
-                      ShadeParams{b, maxb, c->opt.do_mis, c->d_stats, octm, (uint32_t)c->mask_words, overlap ? 1u : 0u}); }
-                { Timed t(c, 5, t3);
-                  pt_launch_compact(c->stream, tiles, q, &c->counts[b], c->alive, nee ? c->shadowm : nullptr,
-                                    c->word_off, c->queue[cur ^ 1], &c->counts[b + 1], c->sq[par], &c->counts[kShadowCount + par],
-                                    c->d_stats, b, last ? 0 : 1, octm, (uint32_t)c->mask_words); }
-                if (overlap) {
-                    HIP_TRY(c, hipEventRecord(c->ev_ready, c->stream));
-                    HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->ev_ready, 0));
-                    { Timed t(c, 3, t3, c->side_stream);
-                      pt_launch_shadow(c->side_stream, blocks, cfg_side, c->sc, c->paths, c->sh[par], c->sq[par],
-                                       &c->counts[kShadowCount + par], nullptr); }
-                    HIP_TRY(c, hipEventRecord(c->ev_shadow[par], c->side_stream));
+                      ms, blocks, c->sc, ln.paths, q, &ln.counts[b], ln.hits, ln.sh[par], ln.alive, ln.shadowm,
+                      ShadeParams{b, maxb, c->opt.do_mis, c->d_stats, octm, (uint32_t)ln.mask_words, side ? 1u : 0u}); }
+                { Timed t(c, 5, t3, ms);
+                  pt_launch_compact(ms, tiles, q, &ln.counts[b], ln.alive, nee ? ln.shadowm : nullptr,
+                                    ln.word_off, ln.queue[cur ^ 1], &ln.counts[b + 1], ln.sq[par], &ln.counts[kShadowCount + par],
+                                    c->d_stats, b, last ? 0 : 1, octm, (uint32_t)ln.mask_words); }
+                if (two_lanes && b == mid_bounce) { HIP_TRY(c, hipEventRecord(ln.ev_mid, ms)); ln.mid_recorded = true; }
+                if (side) {
+                    HIP_TRY(c, hipEventRecord(ln.ev_ready, ms));
+                    HIP_TRY(c, hipStreamWaitEvent(ss, ln.ev_ready, 0));
+                    { Timed t(c, 3, t3, ss);
+                      pt_launch_shadow(ss, blocks, cfg_shadow, c->sc, ln.paths, ln.sh[par], ln.sq[par],
+                                       &ln.counts[kShadowCount + par], nullptr); }
+                    HIP_TRY(c, hipEventRecord(ln.ev_shadow[par], ss));
                 } else if (nee) {
-                    Timed t(c, 3, t3);
-                    pt_launch_shadow(c->stream, blocks, cfg_shadow, c->sc, c->paths, c->sh[0], c->sq[0], &c->counts[kShadowCount], nullptr);
+                    Timed t(c, 3, t3, ms);
+                    pt_launch_shadow(ms, blocks, cfg_shadow, c->sc, ln.paths, ln.sh[0], ln.sq[0], &ln.counts[kShadowCount], nullptr);
                 }
                 cur ^= 1;
             }
-            if (overlap) {                                               // all additions to L are in before it is folded
-                HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_shadow[(maxb - 1) & 1u], 0));
-                if (maxb >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_shadow[maxb & 1u], 0));
+            // all additions to L are in before it is folded; the fold runs on the context's stream, batch after batch
+            const hipStream_t as = c->stream;
+            if (side) {
+                HIP_TRY(c, hipStreamWaitEvent(two_lanes ? ms : as, ln.ev_shadow[(maxb - 1) & 1u], 0));
+                if (maxb >= 2) HIP_TRY(c, hipStreamWaitEvent(two_lanes ? ms : as, ln.ev_shadow[maxb & 1u], 0));
             }
-            { Timed t(c, 6, t3); pt_launch_accumulate(c->stream, blocks, band, frame0, fb, c->paths.L, c->d_out); }
+            if (two_lanes) {
+                HIP_TRY(c, hipEventRecord(ln.ev_done, ms));
+                HIP_TRY(c, hipStreamWaitEvent(as, ln.ev_done, 0));
+            }
+            { Timed t(c, 6, t3, as); pt_launch_accumulate(as, blocks, band, frame0, fb, ln.paths.L, c->d_out); }
+            if (two_lanes) { HIP_TRY(c, hipEventRecord(ln.ev_free, as)); ln.free_recorded = true; }
         }
     }
     HIP_TRY(c, hipGetLastError());
@@ -634,7 +685,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
 int ptmi_synchronize(ptmi_ctx *c) {
     if (!c) return PTMI_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     drain_events(c);
     return PTMI_OK;
 }
@@ -644,7 +695,7 @@ int ptmi_read_output(ptmi_ctx *c, float *dst, size_t n_floats) {
     if (!c->d_out) return fail(c, PTMI_E_STATE, "no output buffer (ptmi_resize)");
     if (n_floats != (size_t)c->W * c->H * 4) return fail(c, PTMI_E_INVALID, "expected %zu floats, got %zu", (size_t)c->W * c->H * 4, n_floats);
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     drain_events(c);
     HIP_TRY(c, hipMemcpy(dst, c->d_out, n_floats * 4, hipMemcpyDeviceToHost));
     return PTMI_OK;
@@ -655,7 +706,7 @@ int ptmi_write_output(ptmi_ctx *c, const float *src, size_t n_floats) {
     if (!c->d_out) return fail(c, PTMI_E_STATE, "no output buffer (ptmi_resize)");
     if (n_floats != (size_t)c->W * c->H * 4) return fail(c, PTMI_E_INVALID, "expected %zu floats, got %zu", (size_t)c->W * c->H * 4, n_floats);
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     HIP_TRY(c, hipMemcpy(c->d_out, src, n_floats * 4, hipMemcpyHostToDevice));
     return PTMI_OK;
 }
@@ -674,7 +725,7 @@ int ptmi_bind_output_device(ptmi_ctx *c, void *p, size_t bytes) {
 
 int ptmi_set_stream(ptmi_ctx *c, void *s) {
     if (!c) return PTMI_E_INVALID;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     drain_events(c);
     c->stream = s ? static_cast<hipStream_t>(s) : c->own_stream;
     return PTMI_OK;
@@ -689,14 +740,14 @@ int ptmi_blit(ptmi_ctx *c, float *dst_f32, size_t n_floats, uint8_t *dst_rgba8, 
     if (dst_rgba8 && n_bytes != n * 4) return fail(c, PTMI_E_INVALID, "8-bit canvas: expected %zu bytes, got %zu", n * 4, n_bytes);
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->blit_px != n) {                                       // staging buffers live in the context (one pair per size)
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, sync_all(c));
         dfree(c->d_blit_f32); dfree(c->d_blit_u8); c->blit_px = 0;
     }
     if (dst_f32 && !c->d_blit_f32) HIP_TRY(c, hipMalloc(&c->d_blit_f32, n * 16));
     if (dst_rgba8 && !c->d_blit_u8) HIP_TRY(c, hipMalloc(&c->d_blit_u8, n * 4));
     c->blit_px = n;
     pt_launch_blit(c->stream, c->n_cu * 8, c->W, c->H, c->d_out, dst_f32 ? c->d_blit_f32 : nullptr, dst_rgba8 ? c->d_blit_u8 : nullptr);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     drain_events(c);
     if (dst_f32) HIP_TRY(c, hipMemcpy(dst_f32, c->d_blit_f32, n * 16, hipMemcpyDeviceToHost));
     if (dst_rgba8) HIP_TRY(c, hipMemcpy(dst_rgba8, c->d_blit_u8, n * 4, hipMemcpyDeviceToHost));
@@ -712,7 +763,7 @@ int ptmi_get_size(const ptmi_ctx *c, uint32_t *w, uint32_t *h) {
 int ptmi_get_stats(ptmi_ctx *c, ptmi_stats *out) {
     if (!c || !out) return PTMI_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     drain_events(c);
     unsigned long long h[kStatsWords];
     HIP_TRY(c, hipMemcpy(h, c->d_stats, sizeof h, hipMemcpyDeviceToHost));
@@ -726,7 +777,7 @@ int ptmi_get_stats(ptmi_ctx *c, ptmi_stats *out) {
 int ptmi_reset_stats(ptmi_ctx *c) {
     if (!c) return PTMI_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     drain_events(c);
     HIP_TRY(c, hipMemset(c->d_stats, 0, kStatsWords * sizeof(unsigned long long)));
     const ptmi_stats old = c->st;
@@ -742,17 +793,19 @@ int ptmi_debug_raygen(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n, const uin
     if (!c || !cam || !xs || !ys || !frames || !o3 || !d3) return PTMI_E_INVALID;
     if (n == 0) return PTMI_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    int rc = ensure_capacity(c, n);
+    Lane &ln = c->lanes[0];                          // the per-stage entry points use the first lane, on the context's stream
+    HIP_TRY(c, sync_all(c));
+    int rc = ensure_capacity(c, ln, n);
     if (rc) return rc;
-    uint32_t *dx = c->queue[0], *dy = c->queue[1], *df = reinterpret_cast<uint32_t *>(c->hits);
+    uint32_t *dx = ln.queue[0], *dy = ln.queue[1], *df = reinterpret_cast<uint32_t *>(ln.hits);
     HIP_TRY(c, hipMemcpyAsync(dx, xs, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(dy, ys, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(df, frames, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    pt_launch_raygen_list(c->stream, *cam, n, dx, dy, df, c->paths);
+    pt_launch_raygen_list(c->stream, *cam, n, dx, dy, df, ln.paths);
     std::vector<float4> o(n), d(n);
-    HIP_TRY(c, hipMemcpyAsync(o.data(), c->paths.O, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(d.data(), c->paths.D, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyAsync(o.data(), ln.paths.O, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d.data(), ln.paths.D, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, sync_all(c));
     for (uint32_t i = 0; i < n; i++) {
         o3[3 * i] = o[i].x; o3[3 * i + 1] = o[i].y; o3[3 * i + 2] = o[i].z;
         d3[3 * i] = d[i].x; d3[3 * i + 1] = d[i].y; d3[3 * i + 2] = d[i].z;
@@ -768,21 +821,25 @@ int ptmi_debug_intersect(ptmi_ctx *c, uint32_t n, const float *o3, const float *
     if (!o3 || !d3 || !t || !tri || !u || !v) return fail(c, PTMI_E_INVALID, "NULL argument");
     if (n == 0) return PTMI_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    rc = ensure_capacity(c, n);
+    Lane &ln = c->lanes[0];                          // the per-stage entry points use the first lane, on the context's stream
+    HIP_TRY(c, sync_all(c));
+    rc = ensure_capacity(c, ln, n);
     if (rc) return rc;
-    rc = upload_rays(c, n, o3, d3, nullptr, c->paths.O, c->paths.D);
+    rc = upload_rays(c, n, o3, d3, nullptr, ln.paths.O, ln.paths.D);
     if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(&c->counts[0], &n, 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&ln.counts[0], &n, 4, hipMemcpyHostToDevice, c->stream));
     TraverseConfig cfg = traverse_config(c, true);
     if (c->opt.traversal == PTMI_TRAVERSAL_LDS && cfg.variant != PT_VARIANT_LDS)
         return fail(c, PTMI_E_UNSUPPORTED, "scene does not fit in LDS");
-    pt_launch_extend(c->stream, c->n_cu * 8, cfg, c->sc, c->paths, nullptr, &c->counts[0], c->hits);
+    if (cfg.wants_spill && !ln.d_spill) HIP_TRY(c, hipMalloc(&ln.d_spill, pt_spill_bytes(c->n_cu * 8)));
+    cfg.spill = ln.d_spill;
+    pt_launch_extend(c->stream, c->n_cu * 8, cfg, c->sc, ln.paths, nullptr, &ln.counts[0], ln.hits);
     // (u, v) are not part of the hit record: rebuilt exactly as `shade` rebuilds them (into the C stream, unused here)
-    pt_launch_hit_uv(c->stream, n, c->sc, c->paths, c->hits, c->paths.C);
+    pt_launch_hit_uv(c->stream, n, c->sc, ln.paths, ln.hits, ln.paths.C);
     std::vector<float2> h(n), uv(n);
-    HIP_TRY(c, hipMemcpyAsync(h.data(), c->hits, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(uv.data(), c->paths.C, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h.data(), ln.hits, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(uv.data(), ln.paths.C, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, sync_all(c));
     HIP_TRY(c, hipGetLastError());
     for (uint32_t i = 0; i < n; i++) {
         t[i] = h[i].x; u[i] = uv[i].x; v[i] = uv[i].y; std::memcpy(&tri[i], &h[i].y, 4);
@@ -796,15 +853,19 @@ int ptmi_debug_occluded(ptmi_ctx *c, uint32_t n, const float *o3, const float *d
     if (!o3 || !d3 || !dist || !occ) return fail(c, PTMI_E_INVALID, "NULL argument");
     if (n == 0) return PTMI_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    rc = ensure_capacity(c, n);
+    Lane &ln = c->lanes[0];                          // the per-stage entry points use the first lane, on the context's stream
+    HIP_TRY(c, sync_all(c));
+    rc = ensure_capacity(c, ln, n);
     if (rc) return rc;
-    rc = upload_rays(c, n, o3, d3, dist, c->sh[0].SO, c->sh[0].SD);
+    rc = upload_rays(c, n, o3, d3, dist, ln.sh[0].SO, ln.sh[0].SD);
     if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(&c->counts[0], &n, 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&ln.counts[0], &n, 4, hipMemcpyHostToDevice, c->stream));
     TraverseConfig cfg = traverse_config(c, false);
-    pt_launch_shadow(c->stream, c->n_cu * 8, cfg, c->sc, c->paths, c->sh[0], nullptr, &c->counts[0], c->d_occ);
-    HIP_TRY(c, hipMemcpyAsync(occ, c->d_occ, n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (cfg.wants_spill && !ln.d_spill) HIP_TRY(c, hipMalloc(&ln.d_spill, pt_spill_bytes(c->n_cu * 8)));
+    cfg.spill = ln.d_spill;
+    pt_launch_shadow(c->stream, c->n_cu * 8, cfg, c->sc, ln.paths, ln.sh[0], nullptr, &ln.counts[0], ln.d_occ);
+    HIP_TRY(c, hipMemcpyAsync(occ, ln.d_occ, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, sync_all(c));
     HIP_TRY(c, hipGetLastError());
     return PTMI_OK;
 }
@@ -885,7 +946,7 @@ int ptmi_debug_math(ptmi_ctx *c, int op, uint32_t n, const float *a, const float
     if (b) { HIP_TRY(c, hipMalloc(&db, bytes)); HIP_TRY(c, hipMemcpy(db, b, bytes, hipMemcpyHostToDevice)); }
     if (cc) { HIP_TRY(c, hipMalloc(&dc, bytes)); HIP_TRY(c, hipMemcpy(dc, cc, bytes, hipMemcpyHostToDevice)); }
     pt_launch_math(c->stream, op, n, da, db, dc, dout);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     HIP_TRY(c, hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
     dfree(da); dfree(db); dfree(dc); dfree(dout);
     return PTMI_OK;
