@@ -80,7 +80,8 @@ typedef struct ptmi_options {
                                    3: additionally each batch is traced as two halves on two lanes (own buffers and streams), the
                                    second started when the first has finished bounce 3, so that a half's last bounces run beside
                                    the next half's first ones; the halves are folded into the output in frame order on the
-                                   context's stream. 2 = library default (currently 3) */
+                                   context's stream (same bits; measured slower than 1, kept for
+                                   experiments). 2 = library default (currently 1) */
     uint32_t reserved[1];
 } ptmi_options;
 

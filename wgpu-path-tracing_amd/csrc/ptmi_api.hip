@@ -586,12 +586,14 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     // adds to L (emissive hits leave a record too, ShadeParams::emit_records), bounce after bounce on one stream, so every
     // path's sum is formed in the same order as without it. Record buffers alternate by bounce parity; shade(b) waits for
     // shadow(b - 2), the end of the batch for the last one.
-    // overlap 3 (the default, 2): additionally every batch is traced as two halves on two lanes (own buffers, own streams), the
+    // overlap 3 (not the default): additionally every batch is traced as two halves on two lanes (own buffers, own streams), the
     // second half started when the first has compacted bounce 3 — the first half's last bounces (a tenth of the rays in queues
     // too small for the machine) then run beside the second half's first ones, and the second half's beside the next
-    // dispatch's. `accumulate` stays on the context's stream, in frame order, after its lane's kernels.
+    // dispatch's. `accumulate` stays on the context's stream, in frame order, after its lane's kernels. Same bits; measured
+    // 10 - 12 % SLOWER on every config (profiles/README.md): two persistent traversal grids, each sized to own every CU's LDS,
+    // take turns instead of sharing.
     const bool side = nee && c->opt.overlap != 0;
-    const bool two_lanes = c->opt.overlap >= 2 && F >= 2;
+    const bool two_lanes = c->opt.overlap == 3 && F >= 2;
     const uint32_t Fsub = two_lanes ? (F + 1) / 2 : F;              // frames per traced batch
     if (npix * Fsub > 0xFFFFFF00ull) return fail(c, PTMI_E_UNSUPPORTED, "batch of %llu paths exceeds 2^32", (unsigned long long)(npix * Fsub));
     const TraverseConfig cfg0 = traverse_config(c, true), cfg_shadow0 = traverse_config(c, false);
