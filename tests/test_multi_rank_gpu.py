@@ -31,3 +31,23 @@ def test_two_ranks_one_gpu_sharded_equals_unsharded():
     from ptmi import shard
     w, h = shard.weak_frame(640, 180, 2)                      # same view, twice the pixels
     assert d["paths"] == w * h * 8 and d["value"] > 0
+
+
+@pytest.mark.gpu
+def test_three_ranks_one_gpu_strong_scaling_of_a_ragged_frame():
+    """bench.py --config 4 (strong scaling: the frame is fixed and split) with three ranks on one GPU and a frame height that
+    is not a whole number of strip rounds for three ranks (110 rows in 4-row strips: shares of 38, 36 and 36 rows; the
+    depth-of-field camera of configs[4]): packed-row gather of unequal shares, rank 0 compares with its own unsharded render."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--config", "4", "--gpus", "3", "--rehearse", "--width", "320",
+           "--height", "110", "--frames-per-step", "3", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 3 and d["scaling"] == "strong" and d["config"]["config_index"] == 4
+    assert d["rehearsal"]["sharded_equals_unsharded_bitwise"] is True
+    assert d["paths"] == 320 * 110 * 6                        # the frame itself, not three times it
