@@ -352,6 +352,7 @@ def main():
             "segments": int(segments), "shadow_rays": int(shadow_rays), "paths": int(paths),
             "shadow_traced_rank0": int(st.shadow_traced),
             "mean_path_length": round(mean_len, 4),
+            "segments_by_bounce_rank0": [int(v) for v in list(st.segments_by_bounce)[:cfg["bounces"]]],
             "nominal_msamples": round(paths * cfg["bounces"] / dt / 1e6, 3),
             "gpu_ms_rank0": round(st.gpu_ms, 3),
             "kernel_ms_rank0": {k: round(v, 3) for k, v in kernel_ms.items()},
