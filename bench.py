@@ -11,9 +11,9 @@
     3  1 M-triangle grid, 1920x1080,  64 spp                      (configs[3]; the only scene that reaches the memory side)
     4  Cornell,          3840x2160, 256 spp, depth of field on (aperture 0.05, focus 2.8)  (configs[4])
 
-One step = one ptmi_dispatch of --frames-per-step frames (default 32, traced as wavefront batches of up to 64 Mi
-paths) over the rank's rows; K defaults to spp / frames-per-step, so the default run renders exactly the config's
-spp. Scene and output live in HBM before the timed region starts (the C ABI copies host blobs at upload).
+One step = one ptmi_dispatch of --frames-per-step frames (default 64, traced as wavefront batches of up to 128 Mi
+paths: at 1920x1080 one batch of 133 M paths) over the rank's rows; K defaults to spp / frames-per-step, so the default
+run renders exactly the config's spp (config 1: ONE step of 64 frames after one warm-up step). Scene and output live in HBM before the timed region starts (the C ABI copies host blobs at upload).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU) shards pixel rows, with no data-path collective (pixels
 and RNG streams are independent, pt.wgsl:719, :753-761); after the last step the strips are gathered to rank 0 with
@@ -52,13 +52,13 @@ PROFILE_TAG = "r02"                     # profiles/<tag>_cfgN_*.json are the cou
 CONFIGS = {
     0: dict(scene="cornell", width=256, height=256, spp=16, fps=16, bounces=4, mis=0, aperture=0.001, focus=5.0,
             scaling="weak", name="configs[0]"),
-    1: dict(scene="cornell", width=1920, height=1080, spp=64, fps=32, bounces=8, mis=1, aperture=0.001, focus=5.0,
+    1: dict(scene="cornell", width=1920, height=1080, spp=64, fps=64, bounces=8, mis=1, aperture=0.001, focus=5.0,
             scaling="weak", name="configs[1]"),
-    2: dict(scene="cornell_spheres", width=1920, height=1080, spp=512, fps=32, bounces=8, mis=1, aperture=0.001, focus=5.0,
+    2: dict(scene="cornell_spheres", width=1920, height=1080, spp=512, fps=64, bounces=8, mis=1, aperture=0.001, focus=5.0,
             scaling="weak", name="configs[2]"),
-    3: dict(scene="grid_1m", width=1920, height=1080, spp=64, fps=32, bounces=8, mis=1, aperture=0.001, focus=5.0,
+    3: dict(scene="grid_1m", width=1920, height=1080, spp=64, fps=64, bounces=8, mis=1, aperture=0.001, focus=5.0,
             scaling="weak", name="configs[3]"),
-    4: dict(scene="cornell", width=3840, height=2160, spp=256, fps=32, bounces=8, mis=1, aperture=0.05, focus=2.8,
+    4: dict(scene="cornell", width=3840, height=2160, spp=256, fps=64, bounces=8, mis=1, aperture=0.05, focus=2.8,
             scaling="strong", name="configs[4]"),
 }
 

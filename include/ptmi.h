@@ -52,7 +52,8 @@ typedef struct ptmi_options {
     uint32_t max_bounces;       /* 1..64; default 8 */
     uint32_t do_mis;            /* 0/1; default 1 */
     uint32_t tile_y0, tile_y1;  /* rows [y0,y1) this context renders; y1 = 0 -> height. Other rows are untouched */
-    uint32_t frames_per_batch;  /* frames traced together as one wavefront batch; 0 -> auto */
+    uint32_t frames_per_batch;  /* frames traced together as one wavefront batch; 0 -> auto (up to 64 frames / ~128 Mi paths, ~23 GB of
+                                   path state at 1920x1080; a dispatch of fewer frames is one smaller batch) */
     uint32_t traversal;         /* PTMI_TRAVERSAL_*; AUTO picks LDS when the scene fits */
     uint32_t cull;              /* 1 (default): ordered traversal with conservative distance cull;
                                    0: every box-overlapping leaf is tested, as pt.wgsl:248-291 does */

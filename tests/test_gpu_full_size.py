@@ -38,7 +38,7 @@ def test_configs1_cornell_1080p_64spp(gpu_ctx, oracle, scene_factory):
     cam = layout.make_camera(W, H)
     gpu_ctx.upload_scene(sc)
     full, st = render(gpu_ctx, cam, frames)
-    assert st.paths == W * H * frames and st.frames == frames and st.frames_per_batch_used == 32
+    assert st.paths == W * H * frames and st.frames == frames and st.frames_per_batch_used == 64
     assert 2.2 < st.segments / st.paths < 2.5 and 0.5 < st.shadow_rays / st.segments < 0.8
     assert np.isfinite(full).all() and 0.05 < full[..., :3].mean() < 0.5 and full[..., :3].max() <= 2.5
 
@@ -75,7 +75,7 @@ def test_configs4_shape_4k_depth_of_field_eight_shares(gpu_ctx, oracle, scene_fa
     cam = layout.make_camera(W, H, aperture=0.05, focus_distance=2.8)
     gpu_ctx.upload_scene(sc)
     full, st = render(gpu_ctx, cam, frames)
-    assert st.paths == W * H * frames and st.frames_per_batch_used == 8
+    assert st.paths == W * H * frames and st.frames_per_batch_used == 16
     for y0, y1 in ((1, 3), (1079, 1082)):
         ref = np.zeros((H, W, 4), np.float32)
         oracle.render(sc, cam, frames, out=ref, y0=y0, y1=y1)
