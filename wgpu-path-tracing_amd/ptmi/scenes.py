@@ -364,7 +364,17 @@ def deep_chain(n=1000, ratio=1.08):
     return _finish("deep_chain", [tris], mats)
 
 
-SCENES = {"cornell": cornell, "cornell_glass": lambda: cornell(glass=True),
+def cornell_enclosed():
+    """The Cornell box inside a closed white room that also holds the camera: no camera ray leaves the scene, so every path
+    survives bounce 0 and the bounce-1 queue is dense (a probe for how much the kernels lose to sparse path ids)."""
+    base = cornell()
+    room = _box((0.0, 2.0, 1.5), (8.0, 6.0, 9.0), 0)
+    for k in ("n0", "n1", "n2"):
+        room[k] = -room[k]                      # the room is seen from inside
+    return _finish("cornell_enclosed", [base.tris, room], base.mats)
+
+
+SCENES = {"cornell": cornell, "cornell_glass": lambda: cornell(glass=True), "cornell_enclosed": cornell_enclosed,
           "cornell_spheres": cornell_spheres, "grid_1m": grid_1m, "feature_box": feature_box, "deep_chain": deep_chain}
 
 
