@@ -1,4 +1,5 @@
-"""BASELINE.json's full-size configurations on the GPU, checked through what does not depend on the size:
+"""BASELINE.json's configurations 1 - 4 on the GPU as written (resolution, frame count, bounces, MIS, depth of field; configs[0]
+runs literally in tests/test_gpu_strict.py), checked through what does not depend on the size:
 * rows cropped out of the full frame equal the oracle's render of exactly those rows (same camera, all frames), bit for bit;
 * the image does not depend on how the work is cut: wavefront batch size, dispatch granularity, interleaved row strips;
 * counters are consistent (paths = W*H*frames, per-part segments add up).
@@ -67,11 +68,11 @@ def test_configs1_cornell_1080p_64spp(gpu_ctx, oracle, scene_factory):
 
 
 def test_configs4_shape_4k_depth_of_field_eight_shares(gpu_ctx, oracle, scene_factory):
-    """BASELINE.json configs[4]'s shape — 3840x2160, aperture 0.05, focus 2.8, rows split over 8 GPUs — at 32 of its
-    256 frames: the eight interleaved shares rendered one after the other equal the single render, and rows of it
-    equal the oracle."""
+    """BASELINE.json configs[4] as written — 3840x2160, all 256 frames, 8 bounces, MIS on, aperture 0.05, focus 2.8, rows
+    split into eight shares (what `bench.py --config 4 --gpus 8` gives each rank: 3-row strips) — the eight shares rendered
+    one after the other on this one GPU equal the single render, and rows of it equal the oracle."""
     sc = scene_factory("cornell")
-    W, H, frames = 3840, 2160, 32
+    W, H, frames = 3840, 2160, 256
     cam = layout.make_camera(W, H, aperture=0.05, focus_distance=2.8)
     gpu_ctx.upload_scene(sc)
     full, st = render(gpu_ctx, cam, frames)
@@ -84,7 +85,7 @@ def test_configs4_shape_4k_depth_of_field_eight_shares(gpu_ctx, oracle, scene_fa
     gpu_ctx.reset_stats()
     seg = []
     for part in range(8):
-        gpu_ctx.set_options(tile_parts=8, tile_part=part, tile_strip=4)
+        gpu_ctx.set_options(tile_parts=8, tile_part=part, tile_strip=3)
         before = gpu_ctx.stats().segments
         gpu_ctx.dispatch(cam, frames)
         seg.append(gpu_ctx.stats().segments - before)
@@ -93,11 +94,11 @@ def test_configs4_shape_4k_depth_of_field_eight_shares(gpu_ctx, oracle, scene_fa
     gpu_ctx.set_options(tile_parts=0, tile_part=0, tile_strip=0)
 
 
-@pytest.mark.parametrize("name,frames,rows", [("cornell_spheres", 64, ((400, 403),)),      # configs[2]: textured PBR spheres, 1024^2 atlas
-                                              ("grid_1m", 16, ((300, 302),))])            # configs[3]: 999 708 triangles, depth-29 BVH
-def test_configs2_and_3_scenes_at_1080p(gpu_ctx, oracle, scene_factory, name, frames, rows):
-    """The two larger scenes of BASELINE.json at full resolution (fewer frames than the configs ask for: the checks
-    are per frame): oracle row crops, ragged batches, interleaved shares."""
+@pytest.mark.parametrize("name,frames,rows", [("cornell_spheres", 512, ((400, 403),)),     # configs[2]: textured PBR spheres, 1024^2 atlas, 512 spp
+                                              ("grid_1m", 64, ((300, 302),))])            # configs[3]: 999 708 triangles, depth-29 BVH, 64 spp
+def test_configs2_and_3_as_written(gpu_ctx, oracle, scene_factory, name, frames, rows):
+    """BASELINE.json configs[2] and configs[3] at their full resolution and frame counts: oracle row crops (the oracle
+    renders only those rows, all frames), ragged batches, interleaved shares."""
     sc = scene_factory(name)
     W, H = 1920, 1080
     cam = layout.make_camera(W, H)
@@ -111,7 +112,7 @@ def test_configs2_and_3_scenes_at_1080p(gpu_ctx, oracle, scene_factory, name, fr
         ref = np.zeros((H, W, 4), np.float32)
         oracle.render(sc, cam, frames, out=ref, y0=y0, y1=y1)
         assert same(full[y0:y1], ref[y0:y1]), f"{name}: rows {y0}..{y1} differ from the oracle"
-    ragged, st2 = render(gpu_ctx, cam, frames, frames_per_batch=5)
+    ragged, st2 = render(gpu_ctx, cam, frames, frames_per_batch=23)
     assert same(ragged, full) and st2.segments == st.segments
     gpu_ctx.resize(W, H)
     gpu_ctx.reset_stats()
