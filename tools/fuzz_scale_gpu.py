@@ -24,7 +24,7 @@ for seed, scale in ((0, 1e-18), (1, 1e-10), (2, 1e-30), (3, 1e8), (4, 1e15), (5,
     cam = layout.make_camera(W, H, aperture=0.0, focus_distance=2.5 * scale)
     cam["position"] = (np.array([0, 1.0, 2.8]) * scale).astype(np.float32)
     ref, ost = oracle.render(sc, cam, frames, max_bounces=8, do_mis=1)
-    for trav in (native.TRAVERSAL_AUTO, native.TRAVERSAL_GLOBAL):
+    for trav in (native.TRAVERSAL_AUTO, native.TRAVERSAL_GLOBAL, native.TRAVERSAL_GLOBAL_EXACT):     # GLOBAL: the quantised image
         ctx.upload_scene(sc); ctx.resize(W, H)
         ctx.set_options(max_bounces=8, do_mis=1, frames_per_batch=0, cull=1, traversal=trav, tile_y0=0, tile_y1=0, tile_parts=0)
         ctx.reset_stats(); ctx.dispatch(cam, frames); got = ctx.read_output(); st = ctx.stats()
