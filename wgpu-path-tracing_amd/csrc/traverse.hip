@@ -6,8 +6,8 @@
 //            (reference: the sceneIntersect calls of pt.wgsl:392/421/463 and the
 //            occlusion predicates of :394/:423/:465)
 //
-// Result contract: the same (t, triangle, u, v) as the reference's
-// traversal — the minimum t over all triangles in leaves whose ancestors all pass
+// Result contract: the same (t, triangle) — and with them the same (u, v), which `shade` recomputes —
+// as the reference's traversal — the minimum t over all triangles in leaves whose ancestors all pass
 // the slab test, ties to the lowest triangle index (= first in the reference's
 // left-first DFS) — reached by an ordered two-box-per-step descent with a
 // conservative distance cull, over a hierarchy rebuilt on the reference's leaves
@@ -20,9 +20,10 @@
 // held hostage by its slowest ray. Per-ray work on Cornell varies widely (measured:
 // max-over-64 / mean = 2.0), which is what this removes.
 //
-// Three memory variants share the body:
+// Memory variants that share the body:
 //   global     : wide nodes / triangle images read through L1/L2; 16 stack entries per lane in LDS, deeper node
-//                stacks spill to global memory (any depth up to the 62 the upload accepts)
+//                stacks spill to global memory (any depth up to the 62 the upload accepts). Scenes beyond an L2 walk
+//                the QUANTISED image (32-byte nodes, leaf stream with the exact leaf boxes, top of the tree in LDS: QuantMem)
 //   lds        : the whole traversal image staged into LDS once per persistent workgroup
 //   node cache : only the wide nodes staged — small trees: two workgroups share a CU; mid-size trees: one
 //                workgroup per CU with spilling stacks
