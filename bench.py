@@ -24,11 +24,12 @@ ONE RCCL gather, inside the timed region. value = all ranks' path segments / max
                across 8x MI355X with RCCL gather").
 Rank r renders the strips r, r + N, ... (4 rows each, fewer when the frame height is not a whole number of such rounds: 3 for 2160 rows over 8 ranks).
 
-Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel (closest-hit traversal `extend`) against HBM:
-algorithmic bytes per ray = 32 (origin+direction float4 pair) + 4 (queue index) + 8 (hit record) = 44 B (DESIGN.md
-§5), launch durations from HIP events recorded by the library on its own stream around every launch
-(`--timing 3`: every kernel, so `kernel_ms_rank0` adds up to `gpu_ms_rank0`); `roofline.kernels` carries the same
-figures for shade and shadow. `roofline.traffic` replays the committed rocprofv3 counter passes of the same command
+Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel against HBM — the kernel with the most device time on
+the stream that carries the bounce loop: on the Cornell scenes `shade` (115 B per segment: queue 4 + hit 8 + ray state 40
+read, 40 written, 48 per emitted record), on the 1 M-triangle scene the closest-hit traversal `extend` (44 B per ray: origin +
+direction 32 + queue index 4 read, hit record 8 written) — with launch durations from HIP events recorded
+by the library around every launch on the stream it runs on (`--timing 3`: every kernel); `roofline.kernels` carries the
+same figures for all three of extend, shade and shadow. `roofline.traffic` replays the committed rocprofv3 counter passes of the same command
 (profiles/<tag>_cfgN_pmc.json, with the commit that made them) — counters cannot be read from inside an un-profiled run.
 `cpu_baseline` times the CPU oracle (oracle/, a restatement — the reference has no CPU path) on a bounded sample of
 the same workload.
@@ -329,6 +330,13 @@ def main():
                            st.shade_launches, st.segments, shade_bytes_per_segment(mis, p_record, b0_share))
         shw = kernel_entry("shadow", "shadow (any-hit visibility of the next-event record)", st.shadow_ms, st.shadow_launches,
                            st.shadow_traced, SHADOW_BYTES_PER_RAY)
+        # The dominant kernel = the one with the most device time on the stream that carries the bounce loop: extend or shade
+        # when the shadow kernel runs beside them on its own stream, any of the three on one stream.
+        overlapped = bool(mis and (args.overlap is None or args.overlap != 0))
+        cands = [(st.extend_ms, ext), (st.shade_ms, shd)] + ([] if overlapped else [(st.shadow_ms, shw)])
+        dom = max((c for c in cands if c[1]), key=lambda c: c[0], default=(0, None))[1]
+        dominant_by = ("most device time among the kernels of the main stream (shadow runs beside them on a second stream)"
+                       if overlapped else "most device time among extend, shade, shadow (one stream)")
         kernel_ms = {"extend": st.extend_ms, "shade": st.shade_ms, "shadow": st.shadow_ms, "raygen": st.raygen_ms,
                      "compact": st.compact_ms, "accumulate": st.accumulate_ms}
         par = f"{strip}-row strips x{world}"
@@ -359,19 +367,19 @@ def main():
             # with the shadow kernel on its own stream (library option overlap, the default with next-event estimation) kernels
             # run beside each other: their HIP-event times then add up to MORE than the dispatch time; --overlap 0 puts
             # everything on one stream, where the sum must equal it
-            "shadow_overlapped": bool(mis and (args.overlap is None or args.overlap != 0)),
+            "shadow_overlapped": overlapped,
             "kernel_ms_sum_over_gpu_ms": round(sum(kernel_ms.values()) / st.gpu_ms, 4) if st.gpu_ms > 0 else None,
             "upload_ms_rank0": {"wall": round(upload_wall_ms, 2), "library": round(st.upload_ms, 2),
                                 "rebuilt_hierarchy": round(st.upload_tree_ms, 2), "copies": round(st.upload_copy_ms, 2)},
             "roofline": {
-                "bound": "hbm", "kernel": ext["kernel"] if ext else None,
-                "achieved": ext["achieved"] if ext else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ext["frac"] if ext else None,
-                "traffic": ext["traffic"] if ext else None,
+                "bound": "hbm", "kernel": dom["kernel"] if dom else None, "dominant_by": dominant_by,
+                "achieved": dom["achieved"] if dom else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dom["frac"] if dom else None,
+                "traffic": dom["traffic"] if dom else None,
                 "traffic_source": traffic_src,
-                **({k: ext[k] for k in ("algorithmic_bytes_per_launch", "bytes_per_unit", "units_per_launch", "avg_launch_ms",
-                                        "launches")} if ext else {}),
-                **({k: ext[k] for k in ("traffic_gbs", "traffic_frac") if k in ext} if ext else {}),
+                **({k: dom[k] for k in ("algorithmic_bytes_per_launch", "bytes_per_unit", "units_per_launch", "avg_launch_ms",
+                                        "launches")} if dom else {}),
+                **({k: dom[k] for k in ("traffic_gbs", "traffic_frac") if k in dom} if dom else {}),
                 "kernels": {k: v for k, v in (("extend", ext), ("shade", shd), ("shadow", shw)) if v},
                 "pipeline_bytes_per_segment": round(b_seg, 1),
                 "pipeline_achieved": round(msamples * 1e6 * b_seg / 1e9, 3),
