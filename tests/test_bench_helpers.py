@@ -93,8 +93,10 @@ def test_committed_bench_lines_keep_the_contract():
         # than it where the shadow kernel runs on its own stream beside the next bounce
         if d["shadow_overlapped"]:
             assert 1.0 <= d["kernel_ms_sum_over_gpu_ms"] < 2.0
-        else:
+        elif d["gpu_ms_rank0"] > 5.0:
             assert abs(d["kernel_ms_sum_over_gpu_ms"] - 1.0) < 0.05
-        for k in ("extend", "shade", "shadow"):
+        else:                                                                  # configs[0]: 0.7 ms in all, launch gaps count
+            assert 0.8 < d["kernel_ms_sum_over_gpu_ms"] <= 1.01
+        for k in ("extend", "shade", "shadow") if d["shadow_traced_rank0"] else ("extend", "shade"):
             e = d["roofline"]["kernels"][k]
             assert e["launches"] > 0 and abs(e["frac"] - e["achieved"] / d["roofline"]["peak"]) < 1e-4
