@@ -3,7 +3,6 @@
 set -o pipefail
 out=gpurun_out/s22; mkdir -p $out
 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_edge_cases.py tests/test_golden.py -m gpu -x -q > $out/pytest.log 2>&1; rc=$?; tail -3 $out/pytest.log; [ $rc = 0 ] || exit $rc
-PTMI_LIB=$PWD/wgpu-path-tracing_amd/lib/ab/libptmi_rot60.so timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > $out/pytest_rot60.log 2>&1; rc=$?; tail -3 $out/pytest_rot60.log; [ $rc = 0 ] || exit $rc
 run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-cpu-baseline "$@" > $out/$tag.json 2> $out/$tag.err || exit 1; python -c "
 import json; d=json.load(open('$out/$tag.json')); print('$tag', d['value'], d['kernel_ms_rank0'], d['gpu_ms_rank0'])"; }
 for i in 1 2 3; do
