@@ -181,8 +181,9 @@ int ptmi_debug_occluded(ptmi_ctx *ctx, uint32_t n, const float *o3, const float 
 /* Host-only (no context, no device): builds the traversal image ptmi_upload_scene would build and reports on it.
  * out[0] wide nodes of the rebuilt hierarchy (0: the tree is walked as uploaded), [1] leaves, [2] its depth,
  * [3] quantised nodes (0: none), [4] dwords of the leaf stream, [5] quantised child boxes that do NOT contain the exact
- * box they stand for (must be 0), [6] mean relative growth of box surface area by the quantisation, [7] leaf headers or
- * triangle records of the stream that differ from the uploaded leaf box / triangles (must be 0). */
+ * box they stand for (must be 0), [6] mean relative growth of box surface area by the quantisation, [7] structural
+ * mismatches (must be 0): leaf headers or triangle records of the stream that differ from the uploaded leaf box / triangles,
+ * inner boxes of the rebuilt hierarchy that are not the exact union of their children's boxes, nodes not reached once. */
 int ptmi_debug_image_stats(const ptmi_triangle *triangles, uint32_t n_triangles,
                            const ptmi_bvh_node *bvh_nodes, uint32_t n_nodes, double out[8]);
 /* arithmetic-contract probe: out[i] = op(a[i], b[i], c[i]) evaluated on the device.

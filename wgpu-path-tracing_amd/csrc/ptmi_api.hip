@@ -931,7 +931,16 @@ int ptmi_debug_image_stats(const ptmi_triangle *tris, uint32_t nt, const ptmi_bv
                     }
                 if (!ok) bad_hdr++;
             } else if (q.w & PT_REF_LEAF) bad_hdr++;
-            else todo.push_back({refs[ch], q.w});
+            else {
+                // an inner box is the exact union of its two children's boxes (what makes any topology equivalent, §3.2)
+                if ((size_t)refs[ch] * 4 + 3 < b.fast_wnodes.size()) {
+                    const float4 *cw = &b.fast_wnodes[(size_t)refs[ch] * 4];
+                    const float clo[3] = {std::min(cw[0].x, cw[1].z), std::min(cw[0].y, cw[1].w), std::min(cw[0].z, cw[2].x)};
+                    const float chi[3] = {std::max(cw[0].w, cw[2].y), std::max(cw[1].x, cw[2].z), std::max(cw[1].y, cw[2].w)};
+                    for (int k = 0; k < 3; k++) if (clo[k] != lo[ch][k] || chi[k] != hi[ch][k]) { bad_hdr++; break; }
+                }
+                todo.push_back({refs[ch], q.w});
+            }
         }
     }
     if (visited != b.qnodes.size() / 2) bad_hdr++;          // every node reached exactly once (a tree: no node can be reached twice)
