@@ -80,7 +80,10 @@ __global__ __launch_bounds__(BLOCK) void k_raygen_list(ptmi_camera cam, uint32_t
 //                 lane L keeps slot 64*w+L iff bit L is set, at base + popcount(bits below L).
 // The next queue is therefore the surviving path ids in unchanged (ascending) order, and its
 // length lands in next_count — no host round trip.
-constexpr int TILE_WORDS = 256;          // 4 waves per tile: many small tiles spread over all CUs
+#ifndef PT_TILE_WORDS
+#define PT_TILE_WORDS 256
+#endif
+constexpr int TILE_WORDS = PT_TILE_WORDS;   // 4 waves per tile: many small tiles spread over all CUs
 constexpr int TILE_WAVES = TILE_WORDS / 64;
 
 __global__ __launch_bounds__(TILE_WORDS) void k_tile_sums(const uint32_t *__restrict__ count_ptr,
