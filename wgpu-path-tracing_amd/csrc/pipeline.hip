@@ -71,19 +71,21 @@ __global__ __launch_bounds__(BLOCK) void k_raygen_list(ptmi_camera cam, uint32_t
 }
 
 // ---- ordered compaction ------------------------------------------------------
-// `shade` leaves one ballot word per 64 queue slots. A tile = 256 words = 16384 slots,
-// one 256-thread workgroup.
+// `shade` leaves one ballot word per 64 queue slots. A tile = 1024 words = 65536 slots,
+// one 1024-thread workgroup.
 //   k_tile_sums : per-tile popcount totals (+ the statistics counters)
 //   k_scatter   : every tile sums the totals of the tiles before it (a few hundred at most),
-//                 scans its own 256 popcounts (wave shuffles + 4 wave totals in LDS), then each
+//                 scans its own 1024 popcounts (wave shuffles + 16 wave totals in LDS), then each
 //                 wave walks its 64 words: word j's mask and base offset are read from lane j,
 //                 lane L keeps slot 64*w+L iff bit L is set, at base + popcount(bits below L).
 // The next queue is therefore the surviving path ids in unchanged (ascending) order, and its
 // length lands in next_count — no host round trip.
+// Measured on config 1 (Msamples/s, same box): 256 words per tile 8 898, 512: 9 133, 1024: 9 160 — with 133 M slots a launch
+// of 8 100 four-wave workgroups costs more than the prefix over fewer, larger tiles.
 #ifndef PT_TILE_WORDS
-#define PT_TILE_WORDS 256
+#define PT_TILE_WORDS 1024
 #endif
-constexpr int TILE_WORDS = PT_TILE_WORDS;   // 4 waves per tile: many small tiles spread over all CUs
+constexpr int TILE_WORDS = PT_TILE_WORDS;   // ballot words (x 64 queue slots) per tile = threads per workgroup
 constexpr int TILE_WAVES = TILE_WORDS / 64;
 
 __global__ __launch_bounds__(TILE_WORDS) void k_tile_sums(const uint32_t *__restrict__ count_ptr,
