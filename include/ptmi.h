@@ -72,7 +72,7 @@ typedef struct ptmi_options {
                                    1: `shade` may use the device's fast reciprocal / reciprocal square root / square root
                                    (1 ulp) instead of the correctly rounded forms. Same RNG streams and control flow; radiance
                                    agrees statistically (tests/test_gpu_perf_mode.py), not bit for bit. Never the headline. */
-    uint32_t ray_sort;          /* 0: queues keep ascending path order; 1: within each compaction tile (16384 slots) surviving rays
+    uint32_t ray_sort;          /* 0: queues keep ascending path order; 1: within each 1024-slot window of the queue surviving rays
                                    are grouped by direction octant before the next traversal (coherent waves; results unchanged);
                                    2 = library default (currently the measured better of the two) */
     uint32_t overlap;           /* 0: every kernel of a dispatch on the context's one stream, in order; 1: the any-hit `shadow` kernel of
