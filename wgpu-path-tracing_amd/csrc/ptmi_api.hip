@@ -612,6 +612,10 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     c->st.traversal_used = cfg0.variant == PT_VARIANT_GLOBAL ? PTMI_TRAVERSAL_GLOBAL : PTMI_TRAVERSAL_LDS;
     c->st.frames_per_batch_used = Fsub;
     const int blocks = c->n_cu * 8;
+#ifndef PT_SHADE_WGS_PER_CU
+#define PT_SHADE_WGS_PER_CU 8
+#endif
+    const int shade_blocks = c->n_cu * PT_SHADE_WGS_PER_CU;      // 256-thread workgroups of the grid-stride shade kernel
     const uint32_t maxb = c->opt.max_bounces;
     const bool sort = c->opt.ray_sort == 1;          // 2 (library default) = off: measured, profiles/README.md
     const bool t1 = c->opt.timing >= 1, t2 = c->opt.timing >= 2, t3 = c->opt.timing >= 3;
@@ -645,7 +649,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
                 if (side && b >= 2) HIP_TRY(c, hipStreamWaitEvent(ms, ln.ev_shadow[par], 0));      // its records are read
                 { Timed t(c, 2, t3, ms);
                   (c->opt.perf_mode ? pt_launch_shade_fast : pt_launch_shade)(
-                      ms, blocks, c->sc, ln.paths, q, &ln.counts[b], ln.hits, ln.sh[par], ln.alive, ln.shadowm,
+                      ms, shade_blocks, c->sc, ln.paths, q, &ln.counts[b], ln.hits, ln.sh[par], ln.alive, ln.shadowm,
                       ShadeParams{b, maxb, c->opt.do_mis, c->d_stats, octm, (uint32_t)ln.mask_words, side ? 1u : 0u}); }
                 { Timed t(c, 5, t3, ms);
                   pt_launch_compact(ms, tiles, q, &ln.counts[b], ln.alive, nee ? ln.shadowm : nullptr,
