@@ -613,9 +613,11 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     c->st.frames_per_batch_used = Fsub;
     const int blocks = c->n_cu * 8;
 #ifndef PT_SHADE_WGS_PER_CU
-#define PT_SHADE_WGS_PER_CU 8
+#define PT_SHADE_WGS_PER_CU 16
 #endif
-    const int shade_blocks = c->n_cu * PT_SHADE_WGS_PER_CU;      // 256-thread workgroups of the grid-stride shade kernel
+    // 256-thread workgroups of the grid-stride shade kernel. Config 1, five interleaved runs each (Msamples/s): 8 per CU 9 247,
+    // 16: 9 362, 32: 9 303, 64: 8 929 (run-to-run +-130); config 3 +-0.
+    const int shade_blocks = c->n_cu * PT_SHADE_WGS_PER_CU;
     const uint32_t maxb = c->opt.max_bounces;
     const bool sort = c->opt.ray_sort == 1;          // 2 (library default) = off: measured, profiles/README.md
     const bool t1 = c->opt.timing >= 1, t2 = c->opt.timing >= 2, t3 = c->opt.timing >= 3;
