@@ -404,7 +404,11 @@ int ptmi_create(int device_ordinal, ptmi_ctx **out) {
         bool ok = true;
         for (Lane &ln : c->lanes) {
             ok = ok && hipStreamCreateWithFlags(&ln.main, hipStreamNonBlocking) == hipSuccess;
+#ifdef PT_SIDE_NORMAL_PRIORITY
+            ok = ok && hipStreamCreateWithFlags(&ln.side, hipStreamNonBlocking) == hipSuccess;
+#else
             ok = ok && hipStreamCreateWithPriority(&ln.side, hipStreamNonBlocking, lo) == hipSuccess;
+#endif
             for (hipEvent_t *e : {&ln.ev_ready, &ln.ev_shadow[0], &ln.ev_shadow[1], &ln.ev_mid, &ln.ev_done, &ln.ev_free})
                 ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
             ok = ok && hipMalloc(&ln.counts, 80 * sizeof(uint32_t)) == hipSuccess;
