@@ -76,7 +76,7 @@ typedef struct ptmi_options {
                                    are grouped by direction octant before the next traversal (coherent waves; results unchanged);
                                    2 = library default (currently the measured better of the two) */
     uint32_t overlap;           /* 0: every kernel of a dispatch on the context's one stream, in order; 1: the any-hit `shadow` kernel of
-                                   bounce b runs on a second (lower-priority) stream beside `extend` / `shade` of bounce b + 1 — it is
+                                   bounce b runs on a second stream beside `extend` / `shade` of bounce b + 1 — it is
                                    the only kernel that adds to the radiance then, in bounce order, so results are unchanged;
                                    3: additionally each batch is traced as two halves on two lanes (own buffers and streams), the
                                    second started when the first has finished bounce 3, so that a half's last bounces run beside

@@ -399,15 +399,18 @@ int ptmi_create(int device_ordinal, ptmi_ctx **out) {
     }
     c->stream = c->own_stream;
     {
-        int lo = 0, hi = 0;                                  // the side streams yield to the main ones
+        // The shadow stream runs at the main stream's priority. At the lowest priority its waves are held back whenever a
+        // main-stream kernel has work to issue; measured, five interleaved runs each (Msamples/s): config 1 lowest 9 173,
+        // equal 9 244 (run-to-run +-130); config 3 lowest 4 744, equal 4 808 (both rounds). -DPT_SIDE_LOW_PRIORITY restores it.
+        int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         bool ok = true;
         for (Lane &ln : c->lanes) {
             ok = ok && hipStreamCreateWithFlags(&ln.main, hipStreamNonBlocking) == hipSuccess;
-#ifdef PT_SIDE_NORMAL_PRIORITY
-            ok = ok && hipStreamCreateWithFlags(&ln.side, hipStreamNonBlocking) == hipSuccess;
-#else
+#ifdef PT_SIDE_LOW_PRIORITY
             ok = ok && hipStreamCreateWithPriority(&ln.side, hipStreamNonBlocking, lo) == hipSuccess;
+#else
+            ok = ok && hipStreamCreateWithFlags(&ln.side, hipStreamNonBlocking) == hipSuccess;
 #endif
             for (hipEvent_t *e : {&ln.ev_ready, &ln.ev_shadow[0], &ln.ev_shadow[1], &ln.ev_mid, &ln.ev_done, &ln.ev_free})
                 ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
