@@ -97,6 +97,16 @@ PT_DEV void open_plain(uint32_t ref, uint32_t &first, uint32_t &cnt, uint32_t &c
 
 PT_DEV bool slab(float bx0, float by0, float bz0, float bx1, float by1, float bz1, v3 o, v3 inv, float &tmin);
 
+// -DPT_UTIL_STATS (a diagnostic build, tools/lane_stats.py; never the shipped library): where a wave's lanes idle. Per kernel
+// kind: [0] votes, [1] lanes holding a ray at the vote, [2] refills, [3] lanes refilled, [4] box-pair steps, [5] lanes taking
+// part, [6] leaves opened (wave steps), [7] lanes opening one, [8] triangle iterations, [9] lanes testing a triangle
+#ifdef PT_UTIL_STATS
+__device__ unsigned long long g_util[2][16];
+#define UTIL(i, v) (ut[i] += (uint32_t)(v))
+#else
+#define UTIL(i, v) ((void)0)
+#endif
+
 struct GlobalMem {
     glb_f4p wn, tp;
     struct RayK {};
@@ -316,6 +326,9 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
     float tlim = 0.0f, limit = __builtin_inff();
     typename Mem::RayK rk{};
     Hit best; best.t = __builtin_inff(); best.tri = PT_REF_NONE;
+#ifdef PT_UTIL_STATS
+    uint32_t ut[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
     for (;;) {
         uint64_t act = ballot(active);
@@ -348,9 +361,11 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                 }
             }
             next += (uint32_t)__popcll(idle);
+            UTIL(2, 1); UTIL(3, popc(ballot(active)) - popc(act));
             act = ballot(active);
         }
         if (act == 0ull && next >= end) break;
+        UTIL(0, 1); UTIL(1, popc(act));
 
         // two entries free (a step files at most two entries) — or, with SPILL, two free once the node entries are moved out
         const bool can_node = active & (cur != PT_REF_NONE) & ((int)room2(lp, sp, stride) | (int)(SPILL && (sp != bot) & room2(lp, bot, stride)));
@@ -368,12 +383,14 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
             bool ct = can_tri;
 #pragma unroll 1
             for (int rep = 0; rep < LEAF_STEPS; rep++) {
+                UTIL(6, 1); UTIL(7, popc(ballot(ct)));
                 if (ct) {
                     lp += stride;                                       // next filed leaf
                     uint32_t first, cnt, cursor;
                     const bool plain = old;          // (a one-leaf tree is never quantised: its root reference is a plain one too)
                     if (!m.open(*lp, plain, o, inv, (CULL && !ANY) ? limit : __builtin_inff(), first, cnt, cursor)) cnt = 0u;
                     for (uint32_t k = 0; k < cnt; k++) {                // pt.wgsl:272-279
+                        UTIL(8, uniform(lane) == lane ? 1 : 0); UTIL(9, 1);   // per-lane counts, summed at the end
                         float4 a, b, c;
                         m.tri(cursor, k, plain, a, b, c);
                         float u = 0.0f, v = 0.0f;
@@ -399,6 +416,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
             bool cn = can_node;
 #pragma unroll
             for (int rep = 0; rep < NODE_STEPS; rep++) {
+                UTIL(4, 1); UTIL(5, popc(ballot(cn)));
                 if (cn) {
                     if (SPILL && !room2(lp, sp, stride)) {              // rare: move the LDS node stack out
                         for (lds_u32p q = bot; q != sp; q += stride) { spill[(size_t)spn * spill_lanes] = *q; spn++; }
@@ -453,6 +471,10 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
         const bool done = active & (occluded | stuck | ((cur == PT_REF_NONE) & (lp == top)));
         if (done) { io.finish(slot, best, occluded); active = false; cur = PT_REF_NONE; lp = top; }
     }
+#ifdef PT_UTIL_STATS
+    if (lane == 0u) for (int i = 0; i < 8; i++) atomicAdd(&g_util[MODE][i], (unsigned long long)ut[i]);
+    for (int i = 8; i < 10; i++) if (ut[i]) atomicAdd(&g_util[MODE][i], (unsigned long long)ut[i]);
+#endif
 }
 
 // ------------------------------------------------------------------ global ----
@@ -604,3 +626,13 @@ size_t pt_spill_bytes(int blocks) {
     const int cus = blocks / 8 > 0 ? blocks / 8 : 1;
     return (size_t)GLOBAL_WGS_MAX * cus * GBLOCK * PT_SPILL_ENTRIES * sizeof(uint32_t);
 }
+
+#ifdef PT_UTIL_STATS
+extern "C" __attribute__((visibility("default"))) int ptmi_debug_util_stats(unsigned long long *out32, int reset) {
+    unsigned long long h[32];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_util), sizeof(h)) != hipSuccess) return 1;
+    for (int i = 0; i < 32; i++) out32[i] = h[i];
+    if (reset) { for (auto &x : h) x = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(g_util), h, sizeof(h)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
