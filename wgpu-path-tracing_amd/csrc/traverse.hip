@@ -57,19 +57,6 @@ constexpr int REFILL_AT = PT_REFILL_AT;   // refill when at most this many of th
 #define PT_LEAF_KEEP 3
 #endif
 constexpr int NODE_STEPS = PT_NODE_STEPS, LEAF_STEPS = PT_LEAF_STEPS, LEAF_KEEP = PT_LEAF_KEEP;
-// FLAT TRIANGLE STREAM: a lane keeps (next triangle, triangles left) of the leaf it has open, and one iteration of the
-// triangle stream tests ONE triangle per lane — a lane whose leaf is used up opens its next filed leaf in the same
-// iteration. A per-leaf loop runs every leaf for as many iterations as the wave's LONGEST leaf (3.1 triangles per leaf on
-// average against 4 at most on Cornell) and idles the lanes that have no leaf filed at that step; measured with
-// -DPT_UTIL_STATS on config 1, extend: 14.3 triangle iterations per 64 rays for 8.5 triangles per ray (59 % of the lanes).
-// Every lane still tests its leaves and their triangles in the same order, so nothing about the result changes.
-#ifndef PT_FLAT_LEAVES
-#define PT_FLAT_LEAVES 1
-#endif
-#ifndef PT_TRI_STEPS
-#define PT_TRI_STEPS 12
-#endif
-constexpr int TRI_STEPS = PT_TRI_STEPS;
 
 // Loads go through address-space-qualified pointers so that the compiler emits ds_read_b128 /
 // global_load_dwordx4 and never a FLAT load: with generic pointers it merged the LDS read of a node
@@ -122,7 +109,6 @@ __device__ unsigned long long g_util[2][16];
 
 struct GlobalMem {
     glb_f4p wn, tp;
-    static constexpr bool FLAT = PT_FLAT_LEAVES != 0;
     struct RayK {};
     PT_DEV static bool in_range(v3, v3) { return true; }
     PT_DEV void prep(v3, v3, RayK &) const {}
@@ -146,7 +132,6 @@ struct GlobalMem {
 template <bool TRIS_IN_LDS>
 struct LdsMem {
     lds_f4p wn, tl; glb_f4p tg;
-    static constexpr bool FLAT = PT_FLAT_LEAVES != 0;
     struct RayK {};
     PT_DEV static bool in_range(v3, v3) { return true; }
     PT_DEV void prep(v3, v3, RayK &) const {}
@@ -195,7 +180,6 @@ struct QuantMem {
     glb_u4p qn; glb_u32p ls; glb_f4p tp;
     float ox, oy, oz, sx, sy, sz;
     lds_u4p qc; uint32_t n_cached;        // the first n_cached nodes (the top levels, numbered breadth-first) also live in LDS
-    static constexpr bool FLAT = false;   // opening a leaf here means a box test: the per-leaf loop keeps it out of the triangle iterations
     struct RayK {};
     PT_DEV static bool in_range(v3, v3) { return true; }
     PT_DEV void prep(v3, v3, RayK &) const {}
@@ -338,7 +322,6 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
     const lds_u32p bot = (lds_u32p)stk, top = bot + (STACK - 1) * stride;
     lds_u32p sp = bot, lp = top;
     uint32_t spn = 0;                       // SPILL: entries of this lane in the spill area
-    uint32_t tcur = 0, tleft = 0;           // flat triangle stream: next triangle of the open leaf, triangles left in it
     v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), inv = mk3(0, 0, 0);
     float tlim = 0.0f, limit = __builtin_inff();
     typename Mem::RayK rk{};
@@ -359,7 +342,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                 const bool want = io.fetch(slot, o, d, tlim);
                 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                 best.t = __builtin_inff(); best.tri = PT_REF_NONE;
-                sp = bot; lp = top; spn = 0u; cur = PT_REF_NONE; tleft = 0u;
+                sp = bot; lp = top; spn = 0u; cur = PT_REF_NONE;
                 limit = (ANY && CULL) ? cull_limit(tlim) : __builtin_inff();      // NaN for a directional light: never culls
                 const bool regular = __builtin_isfinite(inv.x) & __builtin_isfinite(inv.y) & __builtin_isfinite(inv.z) &
                                      (inv.x != 0.0f) & (inv.y != 0.0f) & (inv.z != 0.0f) & Mem::in_range(o, inv);
@@ -386,7 +369,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
 
         // two entries free (a step files at most two entries) — or, with SPILL, two free once the node entries are moved out
         const bool can_node = active & (cur != PT_REF_NONE) & ((int)room2(lp, sp, stride) | (int)(SPILL && (sp != bot) & room2(lp, bot, stride)));
-        const bool can_tri = active & ((lp != top) | (Mem::FLAT && tleft != 0u));
+        const bool can_tri = active & (lp != top);
         const uint64_t bn = ballot(can_node), bt = ballot(can_tri);
         const bool run_tri = popc(bt) > popc(bn);
         bool occluded = false;
@@ -396,38 +379,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
         auto streams = [&](auto with_ref) {
         constexpr bool REF = decltype(with_ref)::value;
         const bool old = REF && use_ref;
-        if (Mem::FLAT && run_tri) {
-            bool ct = can_tri;
-#pragma unroll 1
-            for (int rep = 0; rep < TRI_STEPS; rep++) {
-                UTIL(8, 1); UTIL(9, popc(ballot(ct)));
-                if (ct) {
-                    if (tleft == 0u) {                                  // next filed leaf
-                        lp += stride;
-                        uint32_t first, cnt, cursor;
-                        (void)m.open(*lp, old, o, inv, __builtin_inff(), first, cnt, cursor);
-                        tcur = first; tleft = cnt;
-                    }
-                    float4 a, b, c;                                     // pt.wgsl:272-279, one triangle
-                    m.tri(tcur, 0u, old, a, b, c);
-                    float u = 0.0f, v = 0.0f;
-                    const float t = tri_test(xyz(a), xyz(b), xyz(c), o, d, u, v);
-                    const bool hit = t > 0.0f;
-                    if (ANY) {
-                        occluded = occluded | (hit & !(t >= tlim));
-                    } else {
-                        const bool better = hit & ((t < best.t) | ((t == best.t) & (tcur < best.tri)));
-                        best.t = better ? t : best.t; best.tri = better ? tcur : best.tri;
-                        if (CULL) limit = better ? cull_limit(t) : limit;
-                    }
-                    tcur++; tleft--;
-                }
-                if (rep + 1 < TRI_STEPS) {
-                    ct = ct & ((tleft != 0u) | (lp != top)) & !occluded;
-                    if (popc(ballot(ct)) * LEAF_KEEP < popc(bt)) break;
-                }
-            }
-        } else if (run_tri) {
+        if (run_tri) {
             bool ct = can_tri;
 #pragma unroll 1
             for (int rep = 0; rep < LEAF_STEPS; rep++) {
@@ -516,8 +468,8 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
         else streams(std::false_type{});
         // hang guard: an active lane that can take neither stream (cannot happen while STACK > tree depth) ends here
         const bool stuck = active & !can_node & !can_tri & ((bn | bt) == 0ull);
-        const bool done = active & (occluded | stuck | ((cur == PT_REF_NONE) & (lp == top) & (tleft == 0u)));
-        if (done) { io.finish(slot, best, occluded); active = false; cur = PT_REF_NONE; lp = top; tleft = 0u; }
+        const bool done = active & (occluded | stuck | ((cur == PT_REF_NONE) & (lp == top)));
+        if (done) { io.finish(slot, best, occluded); active = false; cur = PT_REF_NONE; lp = top; }
     }
 #ifdef PT_UTIL_STATS
     if (lane == 0u) for (int i = 0; i < 8; i++) atomicAdd(&g_util[MODE][i], (unsigned long long)ut[i]);
