@@ -277,67 +277,22 @@ PT_DEV LightSample sample_light(const DevScene &sc, uint32_t &rng, v3 hit_pos) {
 }
 
 constexpr int SBLOCK = 256;
-// HIT GATHERING. A miss ends its path without any work (pt.wgsl:646) and on the open Cornell box 27 % of all segments are
-// misses (48 % of the camera rays), so a wave that shades 64 consecutive queue slots idles that share of its lanes through
-// the whole material / light / BSDF code (measured lane utilisation of the kernel's VALU instructions: 0.72). Each wave
-// therefore takes SGROUP = 256 consecutive slots at a time, lists the hits among them in LDS (path, t, triangle, slot
-// offset; ascending), and shades the list 64 entries per round; the per-slot result bits (alive, shadow record written,
-// new direction's octant) are collected in LDS words and written out as the same 64-slot mask words as before. Per-path
-// arithmetic and every output are unchanged.
-#ifndef PT_SHADE_GROUP
-#define PT_SHADE_GROUP 256
-#endif
-#ifndef PT_SHADE_WAVES
-#define PT_SHADE_WAVES 5           /* waves per SIMD asked of the register allocator (0: its own choice) */
-#endif
-#if PT_SHADE_WAVES > 0
-#define PT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES)))
-#else
-#define PT_SHADE_ATTR
-#endif
-constexpr int SGROUP = PT_SHADE_GROUP, SWAVES = SBLOCK / 64;
-enum { B_ALIVE = 0, B_SHADOW, B_NX, B_NY, B_NZ, B_KINDS };
 
-__global__ __launch_bounds__(SBLOCK) PT_SHADE_ATTR void k_shade(DevScene sc, DevPaths P, const uint32_t *__restrict__ queue,
+__global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const uint32_t *__restrict__ queue,
                                                   const uint32_t *__restrict__ count_ptr,
                                                   const float2 *__restrict__ hits, DevShadow S,
                                                   uint64_t *__restrict__ alive_mask,
                                                   uint64_t *__restrict__ shadow_mask, ShadeParams sp) {
-    __shared__ uint4 list_all[SWAVES][SGROUP];
-    __shared__ uint32_t bits_all[SWAVES][B_KINDS][SGROUP / 32];
     const uint32_t count = *count_ptr;
-    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint4 *list = list_all[wave];
-    uint32_t (*bits)[SGROUP / 32] = bits_all[wave];
     uint32_t n_skipped = 0, n_emitted = 0;  // lane 0 of each wave: one atomic per wave at the end
-    for (uint32_t base = (blockIdx.x * SWAVES + wave) * SGROUP; base < count; base += gridDim.x * SWAVES * SGROUP) {
-        if (lane < B_KINDS * (SGROUP / 32)) (&bits[0][0])[lane] = 0u;
-        uint32_t n = 0;                                                      // hits listed so far (the same in all lanes)
-#pragma unroll
-        for (uint32_t c = 0; c < SGROUP / 64; c++) {
-            const uint32_t off = c * 64u + lane, i = base + off;
-            bool is_hit = false;
-            float2 h2 = make_float2(-1.0f, 0.0f);
-            uint32_t p = 0;
-            if (i < count) {
-                h2 = ld_stream(&hits[i]);
-                p = queue ? queue[i] : i;
-                is_hit = !(h2.x < 0.0f);                                     // pt.wgsl:646: miss adds zero
-            }
-            const uint64_t m = __ballot(is_hit);
-            if (is_hit) list[n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = make_uint4(p, __float_as_uint(h2.x), __float_as_uint(h2.y), off);
-            n += (uint32_t)__popcll(m);
-        }
-        for (uint32_t r = 0; r < n; r += 64u) {
-            bool alive = false, shadow = false, skipped = false, emitted = false;
-            bool neg_x = false, neg_y = false, neg_z = false;          // ray_sort: octant of the new direction
-            uint32_t off = 0;
-            if (r + lane < n) {
-                const uint4 ent = list[r + lane];
-                const uint32_t p = ent.x;
-                const float2 h2 = make_float2(__uint_as_float(ent.y), __uint_as_float(ent.z));
-                off = ent.w;
-                const uint32_t i = base + off;
+    for (uint32_t base = blockIdx.x * SBLOCK; base < count; base += gridDim.x * SBLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        bool alive = false, shadow = false, skipped = false, emitted = false;
+        bool neg_x = false, neg_y = false, neg_z = false;          // ray_sort: octant of the new direction
+        if (i < count) {
+            const uint32_t p = queue ? queue[i] : i;
+            const float2 h2 = ld_stream(&hits[i]);
+            if (!(h2.x < 0.0f)) {                                            // pt.wgsl:646: miss adds zero
                 const float4 o4 = ld_stream(&P.O[p]), d4 = ld_stream(&P.D[p]);
                 uint32_t rng = __float_as_uint(o4.w);
                 const v3 ro = xyz(o4), rd = xyz(d4);
@@ -404,31 +359,23 @@ __global__ __launch_bounds__(SBLOCK) PT_SHADE_ATTR void k_shade(DevScene sc, Dev
                     }
                 }
             }
-            const uint32_t word = off >> 5, bit = 1u << (off & 31u);
-            if (alive) atomicOr(&bits[B_ALIVE][word], bit);
-            if (shadow) atomicOr(&bits[B_SHADOW][word], bit);
-            if (sp.octant_masks) {
-                if (neg_x) atomicOr(&bits[B_NX][word], bit);
-                if (neg_y) atomicOr(&bits[B_NY][word], bit);
-                if (neg_z) atomicOr(&bits[B_NZ][word], bit);
-            }
-            const uint64_t zm = __ballot(skipped), em = __ballot(emitted);
+        }
+        const uint64_t am = __ballot(alive), sm = __ballot(shadow), zm = __ballot(skipped), em = __ballot(emitted);
+        if ((threadIdx.x & 63u) == 0u && i < count) {
+            alive_mask[i >> 6] = am;
+            shadow_mask[i >> 6] = sm;
             n_skipped += (uint32_t)__popcll(zm);
             n_emitted += (uint32_t)__popcll(em);
         }
-        // the group's mask words, 64 slots each (a word whose slots lie beyond `count` is not part of the queue)
-        if (lane < SGROUP / 64 && base + lane * 64u < count) {
-            const uint32_t w = (base >> 6) + lane;
-            alive_mask[w] = (uint64_t)bits[B_ALIVE][2u * lane] | ((uint64_t)bits[B_ALIVE][2u * lane + 1u] << 32);
-            shadow_mask[w] = (uint64_t)bits[B_SHADOW][2u * lane] | ((uint64_t)bits[B_SHADOW][2u * lane + 1u] << 32);
-            if (sp.octant_masks) {
-                sp.octant_masks[w] = (uint64_t)bits[B_NX][2u * lane] | ((uint64_t)bits[B_NX][2u * lane + 1u] << 32);
-                sp.octant_masks[sp.octant_stride + w] = (uint64_t)bits[B_NY][2u * lane] | ((uint64_t)bits[B_NY][2u * lane + 1u] << 32);
-                sp.octant_masks[2u * sp.octant_stride + w] = (uint64_t)bits[B_NZ][2u * lane] | ((uint64_t)bits[B_NZ][2u * lane + 1u] << 32);
+        if (sp.octant_masks) {
+            const uint64_t bx = __ballot(neg_x), by = __ballot(neg_y), bz = __ballot(neg_z);
+            if ((threadIdx.x & 63u) == 0u && i < count) {
+                sp.octant_masks[i >> 6] = bx;
+                sp.octant_masks[sp.octant_stride + (i >> 6)] = by;
+                sp.octant_masks[2u * sp.octant_stride + (i >> 6)] = bz;
             }
         }
     }
-    if (lane != 0u) { n_skipped = 0; n_emitted = 0; }
     if (n_skipped) atomicAdd(&sp.stats[1], (unsigned long long)n_skipped);
     if (n_emitted) atomicAdd(&sp.stats[3], (unsigned long long)n_emitted);
 }
