@@ -118,6 +118,38 @@ def pmc_traffic(config, is_profiled_workload):
     return out, src
 
 
+VALU_CLOCK_GHZ = 2.4                    # MI355X_MICROARCH.md: peak engine clock; the chip runs lower under load, so the fraction is a floor
+N_SIMDS = 256 * 4
+
+
+def valu_issue(config, is_profiled_workload, launches, gpu_ms):
+    """The bound the traversal kernels (and, with them beside it, the whole dispatch) actually run against: vector-ALU issue.
+    SQ_ACTIVE_INST_VALU of the committed counter pass (profiles/<tag>_cfgN_counters.json; quad-cycles, summed over all SIMDs,
+    mean per launch) x launches of this step = SIMD-cycles the vector ALUs were busy; / (1024 SIMDs x 2.4 GHz x device time).
+    None when there is no counter file for this workload."""
+    path = profile_path(config, "counters")
+    if not is_profiled_workload or not os.path.exists(path) or gpu_ms <= 0:
+        return None
+    d = json.load(open(path)).get("SQ_ACTIVE_INST_VALU", {})
+    per = {}
+    for label, keys in (("extend", ("k_trace_lds/extend", "k_trace_global/extend")),
+                        ("shadow", ("k_trace_lds/shadow", "k_trace_global/shadow")), ("shade", ("k_shade",))):
+        q = sum(d.get(k, {}).get("avg_per_launch", 0.0) for k in keys)
+        if q:
+            per[label] = q
+    if len(per) < 3:
+        return None
+    busy_ms = {k: 4.0 * q * launches.get(k, 0) / N_SIMDS / (VALU_CLOCK_GHZ * 1e6) for k, q in per.items()}
+    total = sum(busy_ms.values())
+    return {"bound": "valu issue", "busy_ms_per_step_at_peak_clock": {k: round(v, 3) for k, v in busy_ms.items()},
+            "busy_ms_total": round(total, 3), "device_ms": round(gpu_ms, 3), "frac": round(total / gpu_ms, 4),
+            "clock_ghz": VALU_CLOCK_GHZ, "simds": N_SIMDS,
+            "source": {"file": os.path.relpath(path, ROOT), "counter": "SQ_ACTIVE_INST_VALU (quad-cycles per launch, all SIMDs)",
+                       "code_commit": json.load(open(path)).get("_code_commit")},
+            "note": "replayed from the committed counter pass of this command; extend, shade and shadow only (raygen, compaction and "
+                    "accumulate are streaming kernels); the clock under load is below the peak used here, so the true fraction is higher"}
+
+
 def cpu_baseline(scene, cam_kw, width, height, bounces, mis, threads, target_s=12.0):
     """Oracle on whole frames of the same camera: 1 calibration frame, then as many frames as
     fit in about target_s seconds (at most the 64 of the workload)."""
@@ -384,6 +416,9 @@ def main():
                 "pipeline_bytes_per_segment": round(b_seg, 1),
                 "pipeline_achieved": round(msamples * 1e6 * b_seg / 1e9, 3),
                 "pipeline_frac": round(msamples * 1e6 * b_seg / 1e9 / HBM_PEAK_GBS, 6),
+                # the second roofline: how busy the vector ALUs were (counter replay; None without a counter file)
+                "valu_issue": valu_issue(args.config, is_profiled, {"extend": st.extend_launches, "shade": st.shade_launches,
+                                                                  "shadow": st.shadow_launches}, st.gpu_ms),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -61,6 +61,22 @@ def test_committed_counter_files_feed_the_roofline():
     assert b.pmc_traffic(0, True)[0] == {} or os.path.exists(b.profile_path(0, "pmc"))
 
 
+def test_committed_valu_counters_feed_the_second_roofline():
+    """bench.py's roofline.valu_issue replays SQ_ACTIVE_INST_VALU of profiles/<tag>_cfgN_counters.json: a fraction of the
+    vector ALUs' issue capacity between 0 and ~1, per kernel and in all; None for a workload without a counter file."""
+    b = _bench()
+    have = _committed("counters")
+    assert have, f"no profiles/{b.PROFILE_TAG}_cfgN_counters.json committed"
+    for n, path in have:
+        bench_line = json.load(open(b.profile_path(n, "bench")))
+        launches = {k: bench_line["roofline"]["kernels"][k]["launches"] for k in ("extend", "shade", "shadow")}
+        v = b.valu_issue(n, True, launches, bench_line["gpu_ms_rank0"])
+        assert v["bound"] == "valu issue" and 0.3 < v["frac"] < 1.1
+        assert abs(sum(v["busy_ms_per_step_at_peak_clock"].values()) - v["busy_ms_total"]) < 0.01
+        assert b.valu_issue(n, False, launches, 10.0) is None
+    assert b.valu_issue(0, True, {"extend": 4, "shade": 4, "shadow": 0}, 1.0) is None or os.path.exists(b.profile_path(0, "counters"))
+
+
 def _check_line(d):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):

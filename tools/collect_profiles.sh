@@ -2,9 +2,8 @@
 # Copies what tools/sessions/session15.sh left under gpurun_out/ into profiles/ (the tracked evidence of a round).
 # usage: tools/collect_profiles.sh r02
 tag=${1:-r02}; cd "$(dirname "$0")/.."
-for f in gpurun_out/prof_$tag/${tag}_cfg*_{bench,bench_profiled,pmc,per_bounce}.json gpurun_out/prof_$tag/${tag}_cfg1_bench_one_stream.json \
+for f in gpurun_out/prof_$tag/${tag}_cfg*_{bench,bench_profiled,pmc,counters,per_bounce,lane_stats}.json gpurun_out/prof_$tag/${tag}_cfg1_bench_one_stream.json \
          gpurun_out/prof_$tag/${tag}_cfg*_kernel_stats.csv; do [ -s "$f" ] && cp "$f" profiles/; done
-for c in 1 3; do [ -s gpurun_out/pmc_${tag}_cfg$c/summary.json ] && cp gpurun_out/pmc_${tag}_cfg$c/summary.json profiles/${tag}_cfg${c}_counters.json; done
 [ -s gpurun_out/s15/upload.log ] && cp gpurun_out/s15/upload.log profiles/${tag}_upload_times.txt
 python3 - "$tag" <<'PY'
 import json, sys, glob

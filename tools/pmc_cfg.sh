@@ -10,7 +10,7 @@ for grp in "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SAL
   i=$((i+1))
   rocprofv3 --pmc $grp --output-format csv -d $out/g$i -- python3 bench.py --config $cfg --no-cpu-baseline "$@" > /dev/null 2> $out/g$i.err || echo "group $i failed: $grp"
 done
-python3 tools/pmc_summary.py --json $(find $out -name "*counter_collection.csv") > $out/summary.json
+python3 tools/pmc_summary.py --json ${PT_COMMIT:+--commit $PT_COMMIT} $(find $out -name "*counter_collection.csv") > $out/summary.json
 rm -rf $out/g[0-9]
 python3 - <<PY
 import json

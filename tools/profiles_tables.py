@@ -55,7 +55,7 @@ for c in (1, 3, 2, 4):
         print(f"| {k} | {kk['launches']} | {d['kernel_ms_rank0'][k]:.2f} | {n(1e3 * kk['avg_launch_ms'])} | {prof} | {kk['bytes_per_unit']} | "
               f"{kk['units_per_launch'] / 1e6:.2f} M | {n(kk['achieved'])} | {100 * kk['frac']:.1f} % | {tr} | {n(kk.get('traffic_gbs', 0))} |")
     for k in ("raygen", "compact", "accumulate"):
-        st = [stats[s] for s in stats if s.startswith({"raygen": "k_raygen", "compact": "k_s", "accumulate": "k_acc"}[k]) or (k == "compact" and s == "k_tile_sums")]
+        st = [stats[s] for s in stats if s in {"raygen": ("k_raygen",), "compact": ("k_scatter2", "k_scatter", "k_tile_sums"), "accumulate": ("k_accumulate",)}[k]]
         prof = ", ".join(f"{a}" for a in [sum(s[0] for s in st), f"{sum(s[1] for s in st):.2f}"]) if st else "-"
         print(f"| {k} | | {d['kernel_ms_rank0'][k]:.2f} | | {prof} | | | | | | |")
     r = d["roofline"]
@@ -63,6 +63,17 @@ for c in (1, 3, 2, 4):
           f"{100 * r['pipeline_frac']:.1f} % of HBM peak; device time {d['gpu_ms_rank0']:.2f} ms, kernel times add up to "
           f"{d['kernel_ms_sum_over_gpu_ms']:.3f} × that (two streams)."
           + (f" Profiled run's own line: {n(dp['value'])} Msamples/s." if dp else ""))
+    v = r.get("valu_issue")
+    if v:
+        print(f"\nvector-ALU issue ({v['source']['file']}, SQ_ACTIVE_INST_VALU): busy " + ", ".join(f"{k} {x:.2f} ms" for k, x in v["busy_ms_per_step_at_peak_clock"].items())
+              + f" = {v['busy_ms_total']:.2f} ms of {v['device_ms']:.2f} ms device time at {v['clock_ghz']} GHz = **{100 * v['frac']:.1f} %** of the issue capacity of {v['simds']} SIMDs")
+    ls = load(f"cfg{c}_lane_stats.json")
+    if ls:
+        print("\n| lane statistics (diagnostic build) | box-pair steps per ray | lanes in a box step | leaves per ray | triangles per ray | lanes in a triangle iteration | lanes holding a ray at a vote | wave steps per 64 rays: box / leaf / triangle |")
+        print("|---|---|---|---|---|---|---|---|")
+        for k in ("extend", "shadow"):
+            e = ls[k]; w = e["wave_steps_per_64_rays"]
+            print(f"| {k} | {e['box_pair_steps_per_ray']:.2f} | {e['box_step_lane_util']:.2f} | {e['leaves_per_ray']:.2f} | {e['triangles_per_ray']:.2f} | {e['triangle_lane_util']:.2f} | {e['lanes_holding_a_ray_at_vote']:.2f} | {w['box']} / {w['leaf']} / {w['tri']} |")
     pb = load(f"cfg{c}_per_bounce.json")
     if pb:
         seg = d["segments_by_bounce_rank0"]
