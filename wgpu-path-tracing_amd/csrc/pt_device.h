@@ -47,12 +47,12 @@ struct DevScene {
 // ---- path state: 56 B per path, four streams indexed by path id ----
 //   O = (origin.xyz, bits(rng state))   D = (direction.xyz, throughput.x)      the two float4 `extend` reads
 //   C = (throughput.y, throughput.z)    L = (radiance.xyz, 0)
-struct DevPaths { float4 *O, *D; float2 *C; float4 *L; };
+struct DevPaths { float4 *O, *D; float2 *C; float3 *L; };      // L: 12-byte stride (radiance has no fourth lane)
 // hit record, 8 B per queue slot: (t, bits(triangle index)); t = -1 on a miss. `shade` rebuilds (u, v) from the triangle.
-// shadow record, 48 B per queue slot:
+// shadow record, 44 B per queue slot:
 //   SO = (origin.xyz, dist or -1 for directional)  SD = (wi.xyz, bits(path id))
-//   SC = (throughput * directLight .xyz, 0)   added to L[path] when unoccluded
-struct DevShadow { float4 *SO, *SD, *SC; };
+//   SC = throughput * directLight .xyz (12-byte stride)   added to L[path] when unoccluded
+struct DevShadow { float4 *SO, *SD; float3 *SC; };
 
 // The rows one context renders: [y0, y1) of a width x height frame, or — when parts > 1 — every parts-th strip
 // of `strip` rows inside that range, starting with strip number `part` (row bands interleaved across GPUs so each
@@ -121,7 +121,7 @@ void pt_launch_compact(hipStream_t s, int tiles, const uint32_t *queue, const ui
                        unsigned long long *stats, uint32_t bounce, int do_scatter, const uint64_t *octant_masks = nullptr,
                        uint32_t octant_stride = 0);
 void pt_launch_accumulate(hipStream_t s, int blocks, DevBand band, uint32_t frame0, uint32_t n_frames,
-                          const float4 *L, float4 *out);
+                          const float3 *L, float4 *out);
 void pt_launch_blit(hipStream_t s, int blocks, uint32_t W, uint32_t H, const float4 *color, float4 *out_f32,
                     uint32_t *out_rgba8);
 void pt_launch_math(hipStream_t s, int op, uint32_t n, const float *a, const float *b, const float *c, float *out);

@@ -277,8 +277,8 @@ struct ShadowIO {
         if (occluded_out) { occluded_out[i] = occluded ? 1 : 0; return; }
         if (!occluded) {
             uint32_t p = __float_as_uint(S.SD[i].w);
-            float4 l = P.L[p], c = ld_stream(&S.SC[i]);
-            P.L[p] = make_float4(l.x + c.x, l.y + c.y, l.z + c.z, 0.0f);   // pt.wgsl:675
+            const float3 l = P.L[p], c = S.SC[i];
+            P.L[p] = make_float3(l.x + c.x, l.y + c.y, l.z + c.z);   // pt.wgsl:675
         }
     }
 };
