@@ -178,11 +178,11 @@ int ensure_capacity(ptmi_ctx *c, Lane &ln, size_t n) {
     size_t words = cap / 64 + 1;
     size_t tiles = cap / pt_compact_tile_slots() + 2;
     HIP_TRY(c, hipMalloc(&ln.paths.O, cap * 16)); HIP_TRY(c, hipMalloc(&ln.paths.D, cap * 16));
-    HIP_TRY(c, hipMalloc(&ln.paths.C, cap * 8)); HIP_TRY(c, hipMalloc(&ln.paths.L, cap * 12));
+    HIP_TRY(c, hipMalloc(&ln.paths.C, cap * 8)); HIP_TRY(c, hipMalloc(&ln.paths.L, cap * sizeof(rgb_l)));
     HIP_TRY(c, hipMalloc(&ln.hits, cap * 8));
     for (int k = 0; k < 2; k++) {
         HIP_TRY(c, hipMalloc(&ln.sh[k].SO, cap * 16)); HIP_TRY(c, hipMalloc(&ln.sh[k].SD, cap * 16));
-        HIP_TRY(c, hipMalloc(&ln.sh[k].SC, cap * 12)); HIP_TRY(c, hipMalloc(&ln.sq[k], cap * 4));
+        HIP_TRY(c, hipMalloc(&ln.sh[k].SC, cap * sizeof(rgb_sc))); HIP_TRY(c, hipMalloc(&ln.sq[k], cap * 4));
     }
     HIP_TRY(c, hipMalloc(&ln.queue[0], cap * 4)); HIP_TRY(c, hipMalloc(&ln.queue[1], cap * 4));
     HIP_TRY(c, hipMalloc(&ln.alive, words * 8)); HIP_TRY(c, hipMalloc(&ln.shadowm, words * 8));
