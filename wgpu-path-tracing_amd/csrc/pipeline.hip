@@ -42,7 +42,7 @@ PT_DEV void camera_ray(const ptmi_camera &cam, uint32_t x, uint32_t y, uint32_t 
 PT_DEV void init_path(DevPaths P, uint32_t p, v3 o, v3 d, uint32_t rng) {
     P.O[p] = make_float4(o.x, o.y, o.z, __uint_as_float(rng));
     P.D[p] = make_float4(d.x, d.y, d.z, 0.0f);
-    P.L[p] = make_rgb<rgb_l>(0.0f, 0.0f, 0.0f);        // pt.wgsl:640
+    P.stL(p, 0.0f, 0.0f, 0.0f);                        // pt.wgsl:640
 }
 
 // path id = frame_in_batch * band_pixels + local_row * width + x (local rows: DevBand::row_of). The bounce-0 queue is the identity and is
@@ -277,13 +277,13 @@ __global__ __launch_bounds__(TILE_WORDS) void k_scatter_sorted(const uint32_t *_
 
 // pt.wgsl:751-761 for the batch's frames in ascending order
 __global__ __launch_bounds__(BLOCK) void k_accumulate(DevBand band, uint32_t frame0, uint32_t n_frames,
-                                                      const rgb_l *__restrict__ L, float4 *__restrict__ out) {
+                                                      const float *__restrict__ L, uint32_t l_stride, float4 *__restrict__ out) {
     const uint32_t npix = band.rows * band.width;
     for (uint32_t pix = blockIdx.x * BLOCK + threadIdx.x; pix < npix; pix += gridDim.x * BLOCK) {
         const size_t oi = (size_t)band.row_of(pix / band.width) * band.width + pix % band.width;
         float4 acc = out[oi];
         for (uint32_t k = 0; k < n_frames; k++) {
-            const rgb_l l = L[(size_t)k * npix + pix];
+            const rgb_sc l = *reinterpret_cast<const rgb_sc *>(L + ((size_t)k * npix + pix) * l_stride);
             float cx = min1(l.x, 2.5f), cy = min1(l.y, 2.5f), cz = min1(l.z, 2.5f);
             uint32_t frame = frame0 + k;
             if (frame > 0u) {
@@ -406,8 +406,8 @@ void pt_launch_compact(hipStream_t s, int tiles, const uint32_t *queue, const ui
                            shadow_mask, shadow_sums, shadow_queue, shadow_count);
 }
 void pt_launch_accumulate(hipStream_t s, int blocks, DevBand band, uint32_t frame0, uint32_t n_frames,
-                          const rgb_l *L, float4 *out) {
-    hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(BLOCK), 0, s, band, frame0, n_frames, L, out);
+                          const float *L, uint32_t l_stride, float4 *out) {
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(BLOCK), 0, s, band, frame0, n_frames, L, l_stride, out);
 }
 void pt_launch_blit(hipStream_t s, int blocks, uint32_t W, uint32_t H, const float4 *color, float4 *out_f32,
                     uint32_t *out_rgba8) {

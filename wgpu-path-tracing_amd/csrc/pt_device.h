@@ -47,26 +47,25 @@ struct DevScene {
 // ---- path state: 56 B per path, four streams indexed by path id ----
 //   O = (origin.xyz, bits(rng state))   D = (direction.xyz, throughput.x)      the two float4 `extend` reads
 //   C = (throughput.y, throughput.z)    L = (radiance.xyz, 0)
-// Radiance L and the contribution of a shadow record SC have three lanes; whether they are stored at 12- or 16-byte stride is
-// a build choice per buffer (measured below where the defaults are set).
-#ifndef PT_L_BYTES
-#define PT_L_BYTES 12
-#endif
-#ifndef PT_SC_BYTES
-#define PT_SC_BYTES 12
-#endif
-template <int BYTES> struct Rgb;
-template <> struct Rgb<12> { float x, y, z; };
-template <> struct alignas(16) Rgb<16> { float x, y, z, w; };
-typedef Rgb<PT_L_BYTES> rgb_l;
-typedef Rgb<PT_SC_BYTES> rgb_sc;
-template <class T> PT_HD T make_rgb(float x, float y, float z) { T r{}; r.x = x; r.y = y; r.z = z; return r; }
-struct DevPaths { float4 *O, *D; float2 *C; rgb_l *L; };
+// Radiance L and the contribution SC of a shadow record have three lanes and are stored as three floats.
+// SC (read and written in queue-slot order) sits at 12-byte stride. L is read-modify-written by path id, scattered, and its
+// stride is chosen per dispatch (DevPaths::l_stride, in floats): 3 where the scene lives in LDS, 4 where the traversal
+// kernels walk it from memory and every extra line the RMW straddles competes with node fetches. Measured, interleaved runs,
+// Msamples/s (both 16 B / both 12 B / L 16 + SC 12 / L 12 + SC 16): config 1 8 907 / 9 172 / 9 031 / 9 133; config 3
+// 4 742 / 4 524 / 4 734 / 4 482.
+struct rgb_sc { float x, y, z; };
+struct DevPaths {
+    float4 *O, *D; float2 *C; float *L; uint32_t l_stride = 3;
+    __device__ __forceinline__ rgb_sc ldL(uint32_t p) const { return *reinterpret_cast<const rgb_sc *>(L + (size_t)p * l_stride); }
+    __device__ __forceinline__ void stL(uint32_t p, float x, float y, float z) const {
+        *reinterpret_cast<rgb_sc *>(L + (size_t)p * l_stride) = rgb_sc{x, y, z};
+    }
+};
 // hit record, 8 B per queue slot: (t, bits(triangle index)); t = -1 on a miss. `shade` rebuilds (u, v) from the triangle.
 // shadow record, 44 B per queue slot:
 //   SO = (origin.xyz, dist or -1 for directional)  SD = (wi.xyz, bits(path id))
 //   SC = throughput * directLight .xyz (12-byte stride)   added to L[path] when unoccluded
-struct DevShadow { float4 *SO, *SD; rgb_sc *SC; };
+struct DevShadow { float4 *SO, *SD; rgb_sc *SC; };   // 44 B per queue slot
 
 // The rows one context renders: [y0, y1) of a width x height frame, or — when parts > 1 — every parts-th strip
 // of `strip` rows inside that range, starting with strip number `part` (row bands interleaved across GPUs so each
@@ -135,7 +134,7 @@ void pt_launch_compact(hipStream_t s, int tiles, const uint32_t *queue, const ui
                        unsigned long long *stats, uint32_t bounce, int do_scatter, const uint64_t *octant_masks = nullptr,
                        uint32_t octant_stride = 0);
 void pt_launch_accumulate(hipStream_t s, int blocks, DevBand band, uint32_t frame0, uint32_t n_frames,
-                          const rgb_l *L, float4 *out);
+                          const float *L, uint32_t l_stride, float4 *out);
 void pt_launch_blit(hipStream_t s, int blocks, uint32_t W, uint32_t H, const float4 *color, float4 *out_f32,
                     uint32_t *out_rgba8);
 void pt_launch_math(hipStream_t s, int op, uint32_t n, const float *a, const float *b, const float *c, float *out);

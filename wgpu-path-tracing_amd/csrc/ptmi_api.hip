@@ -178,7 +178,7 @@ int ensure_capacity(ptmi_ctx *c, Lane &ln, size_t n) {
     size_t words = cap / 64 + 1;
     size_t tiles = cap / pt_compact_tile_slots() + 2;
     HIP_TRY(c, hipMalloc(&ln.paths.O, cap * 16)); HIP_TRY(c, hipMalloc(&ln.paths.D, cap * 16));
-    HIP_TRY(c, hipMalloc(&ln.paths.C, cap * 8)); HIP_TRY(c, hipMalloc(&ln.paths.L, cap * sizeof(rgb_l)));
+    HIP_TRY(c, hipMalloc(&ln.paths.C, cap * 8)); HIP_TRY(c, hipMalloc(&ln.paths.L, cap * 16));      // room for either stride
     HIP_TRY(c, hipMalloc(&ln.hits, cap * 8));
     for (int k = 0; k < 2; k++) {
         HIP_TRY(c, hipMalloc(&ln.sh[k].SO, cap * 16)); HIP_TRY(c, hipMalloc(&ln.sh[k].SD, cap * 16));
@@ -636,6 +636,10 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
             Lane &ln = c->lanes[two_lanes ? (c->batch_seq & 1u) : 0];
             Lane &other = c->lanes[two_lanes ? ((c->batch_seq & 1u) ^ 1u) : 0];
             c->batch_seq++;
+#ifndef PT_L_STRIDE
+#define PT_L_STRIDE 0              /* 0: by scene (pt_device.h, DevPaths); 3 or 4 floats: fixed */
+#endif
+            ln.paths.l_stride = PT_L_STRIDE ? (uint32_t)PT_L_STRIDE : ((cfg0.quantized || cfg_shadow0.quantized) ? 4u : 3u);
             const hipStream_t ms = two_lanes ? ln.main : c->stream;                   // where this batch's kernels go
             const hipStream_t ss = side ? ln.side : ms;                               // ... and its shadow kernels
             const int tiles = (int)(ln.cap / pt_compact_tile_slots() + 1);
@@ -688,7 +692,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
                 HIP_TRY(c, hipEventRecord(ln.ev_done, ms));
                 HIP_TRY(c, hipStreamWaitEvent(as, ln.ev_done, 0));
             }
-            { Timed t(c, 6, t3, as); pt_launch_accumulate(as, blocks, band, frame0, fb, ln.paths.L, c->d_out); }
+            { Timed t(c, 6, t3, as); pt_launch_accumulate(as, blocks, band, frame0, fb, ln.paths.L, ln.paths.l_stride, c->d_out); }
             if (two_lanes) { HIP_TRY(c, hipEventRecord(ln.ev_free, as)); ln.free_recorded = true; }
         }
     }

@@ -306,11 +306,11 @@ __global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const
                     if (sp.emit_records) {          // the path ends here: its last addition to L, made by `shadow` in bounce order
                         st_stream(&S.SO[i], make_float4(0.0f, 0.0f, 0.0f, -2.0f));
                         st_stream(&S.SD[i], make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(p)));
-                        S.SC[i] = make_rgb<rgb_sc>(e.x, e.y, e.z);
+                        S.SC[i] = rgb_sc{e.x, e.y, e.z};
                         shadow = true; emitted = true;
                     } else {
-                        const rgb_l l = P.L[p];
-                        P.L[p] = make_rgb<rgb_l>(l.x + e.x, l.y + e.y, l.z + e.z);
+                        const rgb_sc l = P.ldL(p);
+                        P.stL(p, l.x + e.x, l.y + e.y, l.z + e.z);
                     }
                 } else {
                     if (sp.do_mis && sc.n_lights > 0u && hit.transmission == 0.0f && hit.is_front) {   // pt.wgsl:661
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const
                                 v3 so = madd3(ls.wi, PT_EPS, hit.position);
                                 st_stream(&S.SO[i], make_float4(so.x, so.y, so.z, ls.dist));
                                 st_stream(&S.SD[i], make_float4(ls.wi.x, ls.wi.y, ls.wi.z, __uint_as_float(p)));
-                                S.SC[i] = make_rgb<rgb_sc>(contrib.x, contrib.y, contrib.z);
+                                S.SC[i] = rgb_sc{contrib.x, contrib.y, contrib.z};
                                 shadow = true;
                             } else {
                                 skipped = true;

@@ -277,9 +277,8 @@ struct ShadowIO {
         if (occluded_out) { occluded_out[i] = occluded ? 1 : 0; return; }
         if (!occluded) {
             uint32_t p = __float_as_uint(S.SD[i].w);
-            const rgb_l l = P.L[p];
-            const rgb_sc c = S.SC[i];
-            P.L[p] = make_rgb<rgb_l>(l.x + c.x, l.y + c.y, l.z + c.z);   // pt.wgsl:675
+            const rgb_sc l = P.ldL(p), c = S.SC[i];
+            P.stL(p, l.x + c.x, l.y + c.y, l.z + c.z);   // pt.wgsl:675
         }
     }
 };
