@@ -283,7 +283,10 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(DevBand band, uint32_t fra
         const size_t oi = (size_t)band.row_of(pix / band.width) * band.width + pix % band.width;
         float4 acc = out[oi];
         for (uint32_t k = 0; k < n_frames; k++) {
-            const rgb_sc l = *reinterpret_cast<const rgb_sc *>(L + ((size_t)k * npix + pix) * l_stride);
+            const size_t li = (size_t)k * npix + pix;
+            rgb_sc l;
+            if (l_stride == 4u) { const float4 v = reinterpret_cast<const float4 *>(L)[li]; l = rgb_sc{v.x, v.y, v.z}; }
+            else l = reinterpret_cast<const rgb_sc *>(L)[li];
             float cx = min1(l.x, 2.5f), cy = min1(l.y, 2.5f), cz = min1(l.z, 2.5f);
             uint32_t frame = frame0 + k;
             if (frame > 0u) {
