@@ -67,8 +67,6 @@ struct DevPaths {
         else reinterpret_cast<rgb_sc *>(L)[p] = rgb_sc{x, y, z};
     }
 };
-    }
-};
 // hit record, 8 B per queue slot: (t, bits(triangle index)); t = -1 on a miss. `shade` rebuilds (u, v) from the triangle.
 // shadow record, 44 B per queue slot:
 //   SO = (origin.xyz, dist or -1 for directional)  SD = (wi.xyz, bits(path id))
