@@ -26,7 +26,7 @@ Rank r renders the strips r, r + N, ... (4 rows each, fewer when the frame heigh
 
 Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel against HBM — the kernel with the most device time on
 the stream that carries the bounce loop: on the Cornell scenes `shade` (115 B per segment: queue 4 + hit 8 + ray state 40
-read, 40 written, 48 per emitted record), on the 1 M-triangle scene the closest-hit traversal `extend` (44 B per ray: origin +
+read, 40 written, 44 per emitted record), on the 1 M-triangle scene the closest-hit traversal `extend` (44 B per ray: origin +
 direction 32 + queue index 4 read, hit record 8 written) — with launch durations from HIP events recorded
 by the library around every launch on the stream it runs on (`--timing 3`: every kernel); `roofline.kernels` carries the
 same figures for all three of extend, shade and shadow. `roofline.traffic` replays the committed rocprofv3 counter passes of the same command
@@ -46,7 +46,13 @@ sys.path.insert(0, os.path.join(ROOT, "wgpu-path-tracing_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 EXTEND_BYTES_PER_RAY = 32 + 4 + 8       # queue 4 + O,D 32 read, hit record (t, triangle) 8 written
-SHADOW_BYTES_PER_RAY = 4 + 48 + 32      # index 4 + record 48 read, radiance RMW 32 (unoccluded)
+SHADOW_RECORD_BYTES = 44                # origin + distance 16, direction + path id 16, contribution 12
+
+
+def shadow_bytes_per_ray(l_bytes=12):
+    """index 4 + record 44 read, radiance read-modify-write (unoccluded): 2 x 12, or 2 x 16 where the library stores the
+    per-path radiance at 16-byte stride (scenes walked from memory; ptmi_stats.radiance_stride_bytes)."""
+    return 4 + SHADOW_RECORD_BYTES + 2 * l_bytes
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
 PROFILE_TAG = "r02"                     # profiles/<tag>_cfgN_*.json are the counter passes replayed in `roofline`
 
@@ -66,20 +72,21 @@ CONFIGS = {
 
 def shade_bytes_per_segment(do_mis, p_record, bounce0_share):
     """queue 4 + hit 8 + O,D,C 40 read, O,D,C 40 written (survivors; priced for every segment), ballots 1/4,
-    + 48 per emitted shadow record; bounce 0 reads neither a queue nor a stored throughput (C)."""
-    b = 4 + 8 + 40 + 40 + 0.25 + (48 * p_record if do_mis else 0.0)
+    + 44 per emitted shadow record; bounce 0 reads neither a queue nor a stored throughput (C)."""
+    b = 4 + 8 + 40 + 40 + 0.25 + (SHADOW_RECORD_BYTES * p_record if do_mis else 0.0)
     return b - bounce0_share * (4 + 8)
 
 
-def pipeline_bytes_per_segment(do_mis, mean_len):
+def pipeline_bytes_per_segment(do_mis, mean_len, l_bytes=12):
     """SURVEY.md §8(d) re-derived for this build's records:
     extend R 32+4 W 8; shade R 4+8+40 (O,D,C) W 40 + masks 0.25; compact R 4 W 4;
-    MIS: shadow record W 48 R 48 + radiance RMW 32; per path: raygen W 48 (O, D, L), accumulate R 16 + frame RMW 32,
-    less what bounce 0 does not touch (the identity queue, 3 x 4, and the stored part of the throughput, 8)."""
+    MIS: shadow record W 44 R 44 + radiance RMW 2 x l_bytes; per path: raygen W 32 + l_bytes (O, D, L), accumulate
+    R l_bytes + frame RMW 32, less what bounce 0 does not touch (the identity queue, 3 x 4, and the stored part of the
+    throughput, 8). l_bytes: 12, or 16 for scenes walked from memory."""
     seg = (32 + 4 + 8) + (4 + 8 + 40 + 40) + 8
     if do_mis:
-        seg += 48 + 48 + 32
-    return seg + (48 + 48 - 12 - 8) / max(mean_len, 1e-9)
+        seg += 2 * SHADOW_RECORD_BYTES + 2 * l_bytes
+    return seg + ((32 + l_bytes) + (l_bytes + 32) - 12 - 8) / max(mean_len, 1e-9)
 
 
 def _git_commit_of(path):
@@ -335,7 +342,8 @@ def main():
     if rank == 0:
         mean_len = segments / paths
         msamples = segments / dt / 1e6
-        b_seg = pipeline_bytes_per_segment(mis, mean_len)
+        l_bytes = int(st.radiance_stride_bytes) or 12
+        b_seg = pipeline_bytes_per_segment(mis, mean_len, l_bytes)
         is_profiled = (not overridden and world == 1 and args.traversal == "auto" and args.steps is None
                        and not args.perf_mode and args.sort is None and args.overlap is None and not args.keep_reference_tree
                        and args.frames_per_batch == 0)
@@ -361,7 +369,7 @@ def main():
         shd = kernel_entry("shade", "shade (material, next-event record, BSDF sample, Russian roulette)", st.shade_ms,
                            st.shade_launches, st.segments, shade_bytes_per_segment(mis, p_record, b0_share))
         shw = kernel_entry("shadow", "shadow (any-hit visibility of the next-event record)", st.shadow_ms, st.shadow_launches,
-                           st.shadow_traced, SHADOW_BYTES_PER_RAY)
+                           st.shadow_traced, shadow_bytes_per_ray(l_bytes))
         # The dominant kernel = the one with the most device time on the stream that carries the bounce loop: extend or shade
         # when the shadow kernel runs beside them on its own stream, any of the three on one stream.
         overlapped = bool(mis and (args.overlap is None or args.overlap != 0))

@@ -103,7 +103,7 @@ typedef struct ptmi_stats {
     uint32_t bvh_depth;         /* of the uploaded tree */
     uint32_t traversal_used;    /* PTMI_TRAVERSAL_GLOBAL or _LDS */
     uint32_t frames_per_batch_used;
-    uint32_t reserved;
+    uint32_t radiance_stride_bytes;  /* of the last dispatch's per-path radiance buffer: 12, or 16 for scenes walked from memory (was reserved) */
     /* ABI 2 */
     uint64_t shadow_traced;     /* shadow records the any-hit kernel actually traced (shadow_rays minus the zero-contribution ones) */
     uint64_t shade_launches, shadow_launches;

@@ -17,15 +17,17 @@ def _bench():
 def test_byte_model_matches_design():
     b = _bench()
     assert b.EXTEND_BYTES_PER_RAY == 4 + 32 + 8
-    # 44 + 92 + 8 (+128 with MIS) + (48 + 48 - 20) / mean path length
-    assert abs(b.pipeline_bytes_per_segment(1, 2.0) - (272 + 38)) < 1e-9
-    assert abs(b.pipeline_bytes_per_segment(0, 4.0) - (144 + 19)) < 1e-9
+    # 44 + 92 + 8 (+ 2 x 44 + 2 x 12 with MIS) + (44 + 44 - 20) / mean path length; radiance at 16-byte stride: 32 and 48 + 48
+    assert abs(b.pipeline_bytes_per_segment(1, 2.0) - (256 + 34)) < 1e-9
+    assert abs(b.pipeline_bytes_per_segment(0, 4.0) - (144 + 17)) < 1e-9
+    assert abs(b.pipeline_bytes_per_segment(1, 2.0, 16) - (264 + 38)) < 1e-9
+    assert b.shadow_bytes_per_ray() == 4 + 44 + 24 and b.shadow_bytes_per_ray(16) == 4 + 44 + 32
 
 
 def test_shade_byte_model():
     b = _bench()
-    # queue 4 + hit 8 + O,D,C 40 read, 40 written, ballots 1/4, + 48 per emitted shadow record
-    assert abs(b.shade_bytes_per_segment(1, 0.5, 0.0) - (92.25 + 24)) < 1e-9
+    # queue 4 + hit 8 + O,D,C 40 read, 40 written, ballots 1/4, + 44 per emitted shadow record
+    assert abs(b.shade_bytes_per_segment(1, 0.5, 0.0) - (92.25 + 22)) < 1e-9
     assert abs(b.shade_bytes_per_segment(0, 0.5, 1.0) - (92.25 - 12)) < 1e-9       # bounce 0 reads no queue, no stored throughput
 
 

@@ -40,6 +40,7 @@ def test_configs1_cornell_1080p_64spp(gpu_ctx, oracle, scene_factory):
     gpu_ctx.upload_scene(sc)
     full, st = render(gpu_ctx, cam, frames)
     assert st.paths == W * H * frames and st.frames == frames and st.frames_per_batch_used == 64
+    assert st.radiance_stride_bytes == 12                                    # scene in LDS: three floats per path
     assert 2.2 < st.segments / st.paths < 2.5 and 0.5 < st.shadow_rays / st.segments < 0.8
     assert np.isfinite(full).all() and 0.05 < full[..., :3].mean() < 0.5 and full[..., :3].max() <= 2.5
 
@@ -107,6 +108,7 @@ def test_configs2_and_3_as_written(gpu_ctx, oracle, scene_factory, name, frames,
     # mid-size tree: closest hit from the one-workgroup node cache; 1 M triangles: global memory
     assert st.paths == W * H * frames
     assert st.traversal_used == (native.TRAVERSAL_LDS if name == "cornell_spheres" else native.TRAVERSAL_GLOBAL)
+    assert st.radiance_stride_bytes == (12 if name == "cornell_spheres" else 16)     # walked from memory: whole float4 accesses
     assert np.isfinite(full).all() and full[..., :3].mean() > 0.02
     for y0, y1 in rows:
         ref = np.zeros((H, W, 4), np.float32)

@@ -616,8 +616,12 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
         if (cfg0.wants_spill && !ln.d_spill) HIP_TRY(c, hipMalloc(&ln.d_spill, pt_spill_bytes(c->n_cu * 8)));          // 128 MiB on 256 CUs
         if (cfg_shadow0.wants_spill && !ln.d_spill_side) HIP_TRY(c, hipMalloc(&ln.d_spill_side, pt_spill_bytes(c->n_cu * 8)));
     }
+#ifndef PT_L_STRIDE
+#define PT_L_STRIDE 0              /* 0: by scene (pt_device.h, DevPaths); 3 or 4 floats: fixed */
+#endif
     c->st.traversal_used = cfg0.variant == PT_VARIANT_GLOBAL ? PTMI_TRAVERSAL_GLOBAL : PTMI_TRAVERSAL_LDS;
     c->st.frames_per_batch_used = Fsub;
+    c->st.radiance_stride_bytes = 4u * (PT_L_STRIDE ? (uint32_t)PT_L_STRIDE : ((cfg0.quantized || cfg_shadow0.quantized) ? 4u : 3u));
     const int blocks = c->n_cu * 8;
 #ifndef PT_SHADE_WGS_PER_CU
 #define PT_SHADE_WGS_PER_CU 16
@@ -636,10 +640,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
             Lane &ln = c->lanes[two_lanes ? (c->batch_seq & 1u) : 0];
             Lane &other = c->lanes[two_lanes ? ((c->batch_seq & 1u) ^ 1u) : 0];
             c->batch_seq++;
-#ifndef PT_L_STRIDE
-#define PT_L_STRIDE 0              /* 0: by scene (pt_device.h, DevPaths); 3 or 4 floats: fixed */
-#endif
-            ln.paths.l_stride = PT_L_STRIDE ? (uint32_t)PT_L_STRIDE : ((cfg0.quantized || cfg_shadow0.quantized) ? 4u : 3u);
+            ln.paths.l_stride = c->st.radiance_stride_bytes / 4u;
             const hipStream_t ms = two_lanes ? ln.main : c->stream;                   // where this batch's kernels go
             const hipStream_t ss = side ? ln.side : ms;                               // ... and its shadow kernels
             const int tiles = (int)(ln.cap / pt_compact_tile_slots() + 1);

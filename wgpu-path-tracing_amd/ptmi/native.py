@@ -50,7 +50,7 @@ class Stats(ctypes.Structure):
                 ("gpu_ms", ctypes.c_double), ("extend_ms", ctypes.c_double), ("extend_launches", ctypes.c_uint64),
                 ("shade_ms", ctypes.c_double), ("shadow_ms", ctypes.c_double),
                 ("bvh_depth", ctypes.c_uint32), ("traversal_used", ctypes.c_uint32),
-                ("frames_per_batch_used", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("frames_per_batch_used", ctypes.c_uint32), ("radiance_stride_bytes", ctypes.c_uint32),
                 ("shadow_traced", ctypes.c_uint64), ("shade_launches", ctypes.c_uint64), ("shadow_launches", ctypes.c_uint64),
                 ("raygen_ms", ctypes.c_double), ("compact_ms", ctypes.c_double), ("accumulate_ms", ctypes.c_double),
                 ("upload_ms", ctypes.c_double), ("upload_tree_ms", ctypes.c_double), ("upload_copy_ms", ctypes.c_double)]
