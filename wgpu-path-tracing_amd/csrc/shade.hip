@@ -277,8 +277,16 @@ PT_DEV LightSample sample_light(const DevScene &sc, uint32_t &rng, v3 hit_pos) {
 }
 
 constexpr int SBLOCK = 256;
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 0           /* > 0: waves per SIMD asked of the register allocator (94 VGPRs = 5 waves by itself) */
+#endif
+#if PT_SHADE_WAVES > 0
+#define PT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES)))
+#else
+#define PT_SHADE_ATTR
+#endif
 
-__global__ __launch_bounds__(SBLOCK) void k_shade(DevScene sc, DevPaths P, const uint32_t *__restrict__ queue,
+__global__ __launch_bounds__(SBLOCK) PT_SHADE_ATTR void k_shade(DevScene sc, DevPaths P, const uint32_t *__restrict__ queue,
                                                   const uint32_t *__restrict__ count_ptr,
                                                   const float2 *__restrict__ hits, DevShadow S,
                                                   uint64_t *__restrict__ alive_mask,
