@@ -479,13 +479,7 @@ int ptmi_upload_scene(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const
     };
     const bool fast = !b.fast_wnodes.empty();
     hipError_t e = up(&n_tris, tris, (size_t)nt * sizeof(ptmi_triangle));
-    if (e == hipSuccess) {
-        // one all-zero material after the caller's: what an out-of-range material index reads (`shade` clamps the index to it)
-        std::vector<ptmi_material> padded((size_t)nm + 1);
-        if (nm) memcpy(padded.data(), mats, (size_t)nm * sizeof(ptmi_material));
-        memset(&padded[nm], 0, sizeof(ptmi_material));
-        e = up(&n_mats, padded.data(), padded.size() * sizeof(ptmi_material));
-    }
+    if (e == hipSuccess) e = up(&n_mats, mats, (size_t)nm * sizeof(ptmi_material));
     if (e == hipSuccess) e = up(&n_lights, lights, (size_t)nl * sizeof(ptmi_light));
     if (e == hipSuccess) e = up(reinterpret_cast<void **>(&n_wnodes), b.wnodes.data(), b.wnodes.size() * 16);
     if (e == hipSuccess) e = up(reinterpret_cast<void **>(&n_tripos), b.tripos.data(), b.tripos.size() * 16);

@@ -69,8 +69,9 @@ PT_DEV HitInfo make_hitinfo(const DevScene &sc, v3 ro, v3 rd, float t, uint32_t 
     float uvy = fma1(T.uv2[1], v, fma1(T.uv1[1], u, T.uv0[1] * w));
     hi.is_front = dot3(geo_n, rd) < 0.0f;
     uint32_t mi = T.material_index;
-    // an out-of-range index reads the all-zero material the upload keeps after the caller's (ptmi_api.hip); fields are read where used
-    const ptmi_material &m = sc.mats[mi < sc.n_mats ? mi : sc.n_mats];
+    ptmi_material m;
+    if (mi < sc.n_mats) m = sc.mats[mi];
+    else __builtin_memset(&m, 0, sizeof m);
     v4 one; one.x = one.y = one.z = one.w = 1.0f;
     v4 alb = texture_color(sc, m.albedo_map, uvx, uvy, one);
     hi.albedo = mk3(alb.x * m.base_color[0], alb.y * m.base_color[1], alb.z * m.base_color[2]);
@@ -88,8 +89,6 @@ PT_DEV HitInfo make_hitinfo(const DevScene &sc, v3 ro, v3 rd, float t, uint32_t 
         float du1x = T.uv1[0] - T.uv0[0], du1y = T.uv1[1] - T.uv0[1];
         float du2x = T.uv2[0] - T.uv0[0], du2y = T.uv2[1] - T.uv0[1];
         float rr = 1.0f / fma1(du1x, du2y, -(du1y * du2x));
-        const v3 w0 = ld3(T.v0);                        // the edges again (the same subtractions) rather than kept across the texture reads
-        e1 = sub3(ld3(T.v1), w0); e2 = sub3(ld3(T.v2), w0);
         v3 tg = mk3(fma1(e1.x, du2y, -(e2.x * du1y)) * rr, fma1(e1.y, du2y, -(e2.y * du1y)) * rr,
                     fma1(e1.z, du2y, -(e2.z * du1y)) * rr);
         tg = normalize3(tg);
