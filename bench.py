@@ -121,7 +121,8 @@ def pmc_traffic(config, is_profiled_workload):
         if n:
             out[label] = int((2 * f + w) / n * 1024)
     src = {"file": os.path.relpath(path, ROOT), "file_commit": _git_commit_of(path), "code_commit": d.get("_code_commit"),
-           "formula": "2*FETCH_SIZE + WRITE_SIZE, bytes per launch (mean over the profiled run's launches)"}
+           "formula": "2*FETCH_SIZE + WRITE_SIZE, bytes per launch (mean over the launches of the profiled run: this config's "
+                      "dispatch, one warm-up and one timed step)"}
     return out, src
 
 
@@ -344,7 +345,9 @@ def main():
         msamples = segments / dt / 1e6
         l_bytes = int(st.radiance_stride_bytes) or 12
         b_seg = pipeline_bytes_per_segment(mis, mean_len, l_bytes)
-        is_profiled = (not overridden and world == 1 and args.traversal == "auto" and args.steps is None
+        # the counter files hold per-launch means of this config's dispatch; every step is such a dispatch (64 more frames of the
+        # same view), so they apply whatever --steps / --warmup are; any flag that changes the dispatch itself rules them out
+        is_profiled = (not overridden and world == 1 and args.traversal == "auto"
                        and not args.perf_mode and args.sort is None and args.overlap is None and not args.keep_reference_tree
                        and args.frames_per_batch == 0)
         traffic, traffic_src = pmc_traffic(args.config, is_profiled)
