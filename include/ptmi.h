@@ -188,9 +188,15 @@ int ptmi_debug_image_stats(const ptmi_triangle *triangles, uint32_t n_triangles,
                            const ptmi_bvh_node *bvh_nodes, uint32_t n_nodes, double out[8]);
 /* arithmetic-contract probe: out[i] = op(a[i], b[i], c[i]) evaluated on the device.
  * ops: 0 a/b, 1 sqrt(a), 2 fma(a,b,c), 3 min(a,b), 4 max(a,b), 5 sin(a), 6 cos(a),
- *      7 pow5(a), 8 f32(u32 bits of a), 9 u32(a) as bits, 10 a - trunc(a), 11 tan(a) */
+ *      7 pow5(a), 8 f32(u32 bits of a), 9 u32(a) as bits, 10 a - trunc(a), 11 tan(a), 12 1/a (the kernels' short form) */
 int ptmi_debug_math(ptmi_ctx *ctx, int op, uint32_t n, const float *a, const float *b,
                     const float *c, float *out);
+/* The kernels compute 1/x and sqrt(x) with short instruction sequences where the operand's magnitude is within
+ * [2^-100, 2^100] and with the compiler's IEEE expansions elsewhere (csrc/pt_math.h). This runs both over ALL 2^32 float bit
+ * patterns on the device and reports how many inputs give different bits (two NaNs count as equal) and the smallest such
+ * pattern: which = 0: 1/x; 1: sqrt(x); 2: the 1/x of the triangle test, whose result is only used for |x| >= 1e-6.
+ * The arithmetic contract (correctly rounded results, as the CPU oracle's '/' and sqrtf) holds iff all three report 0. */
+int ptmi_debug_exact_math(ptmi_ctx *ctx, int which, uint64_t *n_different, uint32_t *first_different);
 
 #ifdef __cplusplus
 }

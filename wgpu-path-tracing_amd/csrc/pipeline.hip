@@ -29,7 +29,7 @@ PT_DEV void camera_ray(const ptmi_camera &cam, uint32_t x, uint32_t y, uint32_t 
     org = pos;
     if (cam.aperture > 0.0f) {
         v3 focal = madd3(dir, cam.focus_distance, pos);
-        float r = __builtin_sqrtf(rng_f(rng)) * cam.aperture;
+        float r = sqrt1(rng_f(rng)) * cam.aperture;
         float theta = rng_f(rng) * 2.0f * PT_PI;
         float st, ct; sincos1(theta, st, ct);
         v3 off = madd3(up, r * st, scale3(rt, r * ct));
@@ -357,7 +357,7 @@ __global__ void k_math(int op, uint32_t n, const float *a, const float *b, const
     float x = a[i], y = b ? b[i] : 0.0f, z = c ? c[i] : 0.0f, r = 0.0f, t;
     switch (op) {
     case 0: r = x / y; break;
-    case 1: r = __builtin_sqrtf(x); break;
+    case 1: r = sqrt1(x); break;
     case 2: r = fma1(x, y, z); break;
     case 3: r = min1(x, y); break;
     case 4: r = max1(x, y); break;
@@ -368,13 +368,33 @@ __global__ void k_math(int op, uint32_t n, const float *a, const float *b, const
     case 9: r = __uint_as_float(f2u(x)); break;
     case 10: r = x - __builtin_truncf(x); break;
     case 11: r = tan1(x); break;
+    case 12: r = rcp1(x); break;
     default: break;
     }
     out[i] = r;
 }
 
+// The short forms of 1/x and sqrt(x) (pt_math.h) against the compiler's IEEE expansions, on every float there is:
+// which = 0: rcp1(x) vs 1.0f / x; 1: sqrt1(x) vs sqrtf(x); 2: rcp1_above_eps(x) vs 1.0f / x for |x| >= PT_EPS or NaN.
+// out[0] = inputs whose results differ in any bit (two NaNs count as equal), out[1] = the smallest such bit pattern.
+__global__ void k_exact_math(int which, unsigned long long *out) {
+    unsigned long long bad = 0, first = ~0ull;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < (1ull << 32); i += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((uint32_t)i);
+        float got, ref;
+        if (which == 1) { got = sqrt1(x); ref = __builtin_sqrtf(x); }
+        else if (which == 2) { if (__builtin_fabsf(x) < PT_EPS) continue; got = rcp1_above_eps(x); ref = 1.0f / x; }
+        else { got = rcp1(x); ref = 1.0f / x; }
+        if (__float_as_uint(got) != __float_as_uint(ref) && !(got != got && ref != ref)) { bad++; first = i < first ? i : first; }
+    }
+    if (bad) { atomicAdd(&out[0], bad); atomicMin(&out[1], first); }
+}
+
 }  // namespace
 
+void pt_launch_exact_math(hipStream_t s, int which, unsigned long long *out) {
+    hipLaunchKernelGGL(k_exact_math, dim3(256 * 16), dim3(256), 0, s, which, out);
+}
 void pt_launch_raygen(hipStream_t s, int blocks, const ptmi_camera &cam, DevBand band, uint32_t frame0,
                       uint32_t n_frames, DevPaths p, uint32_t *count_out) {
     hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(BLOCK), 0, s, cam, band, frame0, n_frames, p, count_out);

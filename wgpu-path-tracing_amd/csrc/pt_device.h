@@ -143,5 +143,6 @@ void pt_launch_accumulate(hipStream_t s, int blocks, DevBand band, uint32_t fram
                           const float *L, uint32_t l_stride, float4 *out);
 void pt_launch_blit(hipStream_t s, int blocks, uint32_t W, uint32_t H, const float4 *color, float4 *out_f32,
                     uint32_t *out_rgba8);
+void pt_launch_exact_math(hipStream_t s, int which, unsigned long long *out);
 void pt_launch_math(hipStream_t s, int op, uint32_t n, const float *a, const float *b, const float *c, float *out);
 

@@ -983,4 +983,19 @@ int ptmi_debug_math(ptmi_ctx *c, int op, uint32_t n, const float *a, const float
     return PTMI_OK;
 }
 
+int ptmi_debug_exact_math(ptmi_ctx *c, int which, uint64_t *n_different, uint32_t *first_different) {
+    if (!c || !n_different || which < 0 || which > 2) return PTMI_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    unsigned long long *d = nullptr, h[2] = {0ull, ~0ull};
+    HIP_TRY(c, hipMalloc(&d, sizeof h));
+    HIP_TRY(c, hipMemcpy(d, h, sizeof h, hipMemcpyHostToDevice));
+    pt_launch_exact_math(c->stream, which, d);
+    HIP_TRY(c, sync_all(c));
+    HIP_TRY(c, hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
+    dfree(d);
+    *n_different = h[0];
+    if (first_different) *first_different = (uint32_t)h[1];
+    return PTMI_OK;
+}
+
 }  // extern "C"

@@ -88,7 +88,7 @@ PT_DEV HitInfo make_hitinfo(const DevScene &sc, v3 ro, v3 rd, float t, uint32_t 
     if (nm.x != 0.5f || nm.y != 0.5f || nm.z != 1.0f) {
         float du1x = T.uv1[0] - T.uv0[0], du1y = T.uv1[1] - T.uv0[1];
         float du2x = T.uv2[0] - T.uv0[0], du2y = T.uv2[1] - T.uv0[1];
-        float rr = 1.0f / fma1(du1x, du2y, -(du1y * du2x));
+        float rr = rcp1(fma1(du1x, du2y, -(du1y * du2x)));
         v3 tg = mk3(fma1(e1.x, du2y, -(e2.x * du1y)) * rr, fma1(e1.y, du2y, -(e2.y * du1y)) * rr,
                     fma1(e1.z, du2y, -(e2.z * du1y)) * rr);
         tg = normalize3(tg);
@@ -105,10 +105,10 @@ PT_DEV HitInfo make_hitinfo(const DevScene &sc, v3 ro, v3 rd, float t, uint32_t 
 
 PT_DEV v3 random_cosine_direction(uint32_t &rng) {             // pt.wgsl:299-307
     float r1 = rng_f(rng), r2 = rng_f(rng);
-    float z = __builtin_sqrtf(1.0f - r2);
+    float z = sqrt1(1.0f - r2);
     float phi = (2.0f * PT_PI) * r1;
     float sp, cp; sincos1(phi, sp, cp);
-    float sr = __builtin_sqrtf(r2);
+    float sr = sqrt1(r2);
     return mk3(cp * sr, sp * sr, z);
 }
 PT_DEV float distribution_ggx(v3 N, v3 H, float roughness) {   // pt.wgsl:316-325
@@ -150,8 +150,8 @@ PT_DEV v3 sample_ggx_normal(uint32_t &rng, v3 normal, float roughness) {   // pt
     float r1 = rng_f(rng), r2 = rng_f(rng);
     float a = roughness * roughness;
     float phi = (2.0f * PT_PI) * r1;
-    float cos_t = __builtin_sqrtf((1.0f - r2) / (1.0f + (a * a - 1.0f) * r2));
-    float sin_t = __builtin_sqrtf(1.0f - cos_t * cos_t);
+    float cos_t = sqrt1((1.0f - r2) / (1.0f + (a * a - 1.0f) * r2));
+    float sin_t = sqrt1(1.0f - cos_t * cos_t);
     float sp, cp; sincos1(phi, sp, cp);
     v3 T, B; construct_tbn(normal, T, B);
     return normalize3(lincomb3(T, sin_t * cp, B, sin_t * sp, normal, cos_t));
@@ -175,12 +175,12 @@ PT_DEV v3 sample_bsdf(uint32_t &rng, const HitInfo &h, v3 rd, bool front) {
         v3 N = sample_ggx_normal(rng, h.normal, rough);
         return reflect3(neg3(V), N);
     } else {
-        float eta = front ? 1.0f / h.ior : h.ior;
+        float eta = front ? rcp1(h.ior) : h.ior;
         float rough = max1(h.roughness, 0.04f);
         v3 N = sample_ggx_normal(rng, h.normal, rough);
         if (!front) N = neg3(N);
         float cos_t = dot3(N, V);
-        float sin_t = __builtin_sqrtf(1.0f - cos_t * cos_t);
+        float sin_t = sqrt1(1.0f - cos_t * cos_t);
         bool cannot_refract = eta * sin_t > 1.0f;
         float F = reflectance(__builtin_fabsf(cos_t), eta);
         if (cannot_refract || (rng_f(rng) < F)) return reflect3(neg3(V), N);   // short-circuit: draw only if needed
@@ -206,7 +206,7 @@ PT_DEV v4 eval_bsdf(const HitInfo &h, v3 normal, v3 V, v3 L, bool front) {
     v3 bsdf = mk3(0.0f, 0.0f, 0.0f);
     float pdf = 0.0f;
     if (h.transmission > 0.0f) {
-        float eta = front ? 1.0f / h.ior : h.ior;
+        float eta = front ? rcp1(h.ior) : h.ior;
         float cos_t = dot3(normal, V);
         float Ft = reflectance(__builtin_fabsf(cos_t), eta);
         bsdf = scale3(h.albedo, 1.0f - Ft);
@@ -233,7 +233,7 @@ PT_DEV LightSample sample_light(const DevScene &sc, uint32_t &rng, v3 hit_pos) {
     ls.intensity = mk3(0.0f, 0.0f, 0.0f); ls.wi = mk3(0.0f, 0.0f, 0.0f); ls.pdf = 0.0f; ls.dist = -1.0f; ls.traced = false;
     const uint32_t nl = sc.n_lights;
     const ptmi_light lt = sc.lights[rng_int(rng, 0u, nl - 1u)];
-    const float inv_n = 1.0f / (float)nl;
+    const float inv_n = rcp1((float)nl);
     if (lt.light_type == PTMI_LIGHT_DIRECTIONAL) {
         ls.wi = normalize3(neg3(ld3(lt.position)));
         ls.intensity = scale3(ld3(lt.color), lt.intensity);
@@ -245,7 +245,7 @@ PT_DEV LightSample sample_light(const DevScene &sc, uint32_t &rng, v3 hit_pos) {
         float dist = length3(to_l);
         if (dist > 100.0f) return ls;
         ls.wi = vdiv3(to_l, dist);
-        float att = 1.0f / (dist * dist);
+        float att = rcp1(dist * dist);
         ls.intensity = scale3(scale3(ld3(lt.color), lt.intensity), att);
         ls.pdf = inv_n * 10000.0f;
         ls.dist = dist;
@@ -255,7 +255,7 @@ PT_DEV LightSample sample_light(const DevScene &sc, uint32_t &rng, v3 hit_pos) {
         if (lt.triangle_index < sc.n_tris) T = sc.tris[lt.triangle_index];
         else __builtin_memset(&T, 0, sizeof T);
         float r1 = rng_f(rng), r2 = rng_f(rng);
-        float sq = __builtin_sqrtf(r1);
+        float sq = sqrt1(r1);
         float u = 1.0f - sq;
         float v = r2 * sq;
         float w = 1.0f - u - v;
@@ -267,7 +267,7 @@ PT_DEV LightSample sample_light(const DevScene &sc, uint32_t &rng, v3 hit_pos) {
         v3 e1 = sub3(ld3(T.v1), ld3(T.v0)), e2 = sub3(ld3(T.v2), ld3(T.v0));
         float area = length3(cross3(e1, e2)) * 0.5f;
         float cos_t = __builtin_fabsf(dot3(n, neg3(wi)));
-        ls.pdf = (inv_n * (1.0f / area)) * (dist * dist / max1(cos_t, PT_EPS));
+        ls.pdf = (inv_n * rcp1(area)) * (dist * dist / max1(cos_t, PT_EPS));
         ls.intensity = scale3(ld3(lt.color), lt.intensity);
         ls.wi = wi;
         ls.dist = dist;
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(SBLOCK) PT_SHADE_ATTR void k_shade(DevScene sc, Dev
                 if (sp.bounce != 0u) { const float2 c2 = ld_stream(&P.C[p]); thr = mk3(d4.w, c2.x, c2.y); }
                 const HitInfo hit = make_hitinfo(sc, ro, rd, h2.x, __float_as_uint(h2.y));
                 if (hit.emission.x > 0.0f || hit.emission.y > 0.0f || hit.emission.z > 0.0f) {   // pt.wgsl:652-658
-                    float att = 1.0f / (1.0f + hit.t * hit.t);
+                    float att = rcp1(1.0f + hit.t * hit.t);
                     float k = hit.emissive_strength;
                     const v3 e = mk3(thr.x * hit.emission.x * k * att, thr.y * hit.emission.y * k * att, thr.z * hit.emission.z * k * att);
                     if (sp.emit_records) {          // the path ends here: its last addition to L, made by `shadow` in bounce order

@@ -340,7 +340,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
             if (!active && vi < end && vslot < count) {
                 slot = vslot;
                 const bool want = io.fetch(slot, o, d, tlim);
-                inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                inv = mk3(rcp1(d.x), rcp1(d.y), rcp1(d.z));
                 best.t = __builtin_inff(); best.tri = PT_REF_NONE;
                 sp = bot; lp = top; spn = 0u; cur = PT_REF_NONE;
                 limit = (ANY && CULL) ? cull_limit(tlim) : __builtin_inff();      // NaN for a directional light: never culls

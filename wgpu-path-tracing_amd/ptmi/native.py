@@ -21,7 +21,7 @@ EXPORTS = [
     "ptmi_upload_atlas", "ptmi_resize", "ptmi_set_options", "ptmi_get_options", "ptmi_dispatch",
     "ptmi_synchronize", "ptmi_read_output", "ptmi_write_output", "ptmi_output_device_ptr",
     "ptmi_bind_output_device", "ptmi_set_stream", "ptmi_blit", "ptmi_get_stats", "ptmi_reset_stats",
-    "ptmi_debug_raygen", "ptmi_debug_intersect", "ptmi_debug_occluded", "ptmi_debug_math", "ptmi_get_size",
+    "ptmi_debug_raygen", "ptmi_debug_intersect", "ptmi_debug_occluded", "ptmi_debug_math", "ptmi_debug_exact_math", "ptmi_get_size",
     "ptmi_debug_image_stats",
 ]
 ABI_VERSION = 2
@@ -102,6 +102,7 @@ def load():
         L.ptmi_debug_intersect.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
         L.ptmi_debug_occluded.argtypes = [vp, u32, vp, vp, vp, vp]
         L.ptmi_debug_math.argtypes = [vp, ctypes.c_int, u32, vp, vp, vp, vp]
+        L.ptmi_debug_exact_math.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
         _lib = L
     return _lib
 
@@ -255,3 +256,10 @@ class Context:
         out = np.zeros_like(a)
         self._ck(self.L.ptmi_debug_math(self.h, op, a.size, _p(a), _p(b), _p(c), _p(out)))
         return out
+
+    def debug_exact_math(self, which):
+        """(inputs among all 2^32 float patterns whose short-form result differs from the IEEE expansion, smallest such pattern);
+        which = 0: 1/x, 1: sqrt(x), 2: the triangle test's 1/x (|x| >= 1e-6). include/ptmi.h."""
+        n, first = ctypes.c_uint64(0), ctypes.c_uint32(0)
+        self._ck(self.L.ptmi_debug_exact_math(self.h, which, ctypes.byref(n), ctypes.byref(first)))
+        return int(n.value), int(first.value)
