@@ -78,13 +78,15 @@ PT_DEV float sqrt_short(float x) {
     const float s = x * r, h = 0.5f * r;
     return __builtin_fmaf(__builtin_fmaf(-s, s, x), h, s);
 }
+// the short form runs unconditionally; the lanes outside its range (almost never any: one scalar branch) redo it the IEEE way
 PT_DEV float rcp1(float x) {
 #if PT_IEEE_EXPANSIONS
     return 1.0f / x;
 #else
     const float ax = __builtin_fabsf(x);
-    if (__builtin_expect((ax >= 0x1p-100f) & (ax <= 0x1p100f), 1)) return rcp_short(x);
-    return 1.0f / x;
+    float r = rcp_short(x);
+    if (__builtin_expect(!((ax >= 0x1p-100f) & (ax <= 0x1p100f)), 0)) r = 1.0f / x;
+    return r;
 #endif
 }
 // 1/x where the caller discards the result for |x| < 1e-6 anyway (tri_test): only the upper end needs the IEEE branch
@@ -92,16 +94,18 @@ PT_DEV float rcp1_above_eps(float x) {
 #if PT_IEEE_EXPANSIONS
     return 1.0f / x;
 #else
-    if (__builtin_expect(__builtin_fabsf(x) <= 0x1p100f, 1)) return rcp_short(x);
-    return 1.0f / x;
+    float r = rcp_short(x);
+    if (__builtin_expect(!(__builtin_fabsf(x) <= 0x1p100f), 0)) r = 1.0f / x;
+    return r;
 #endif
 }
 PT_DEV float sqrt1(float x) {
 #if PT_IEEE_EXPANSIONS
     return __builtin_sqrtf(x);
 #else
-    if (__builtin_expect((x >= 0x1p-100f) & (x <= 0x1p100f), 1)) return sqrt_short(x);
-    return __builtin_sqrtf(x);
+    float r = sqrt_short(x);
+    if (__builtin_expect(!((x >= 0x1p-100f) & (x <= 0x1p100f)), 0)) r = __builtin_sqrtf(x);
+    return r;
 #endif
 }
 
