@@ -104,6 +104,30 @@ def test_extend_parity(gpu_ctx, oracle, scene_factory, name, cull, trav):
     gpu_ctx.set_options(cull=1, traversal=native.TRAVERSAL_AUTO)
 
 
+@pytest.mark.parametrize("trav", ["lds", "global"])
+def test_unbounded_determinants_keep_the_ieee_reciprocal(gpu_ctx, oracle, scene_factory, trav):
+    """The triangle test's 1/a is a short sequence that equals the IEEE quotient for |a| <= 2^100 (tests/test_gpu_math.py), and
+    the traversal drops its range test for rays whose |d|_1 x longest-edge^2 stays below that (csrc/traverse.hip, `unbounded`).
+    Rays that do not — directions scaled by 2^60 ... 2^120 — must take the copy of the loop that keeps the test: t, u, v against
+    the oracle's plain division, bit for bit, mixed in one launch with ordinary unit directions."""
+    from ptmi import native
+    sc = scene_factory("cornell")
+    gpu_ctx.upload_scene(sc)
+    gpu_ctx.set_options(cull=1, traversal=native.TRAVERSAL_GLOBAL if trav == "global" else native.TRAVERSAL_AUTO)
+    o, d = _test_rays(sc, 120_000, 31)
+    rng = np.random.default_rng(32)
+    scale = np.exp2(rng.choice([0, 0, 60, 90, 101, 120], len(d))).astype(np.float32)
+    d = (d * scale[:, None]).astype(np.float32)
+    gt, gtri, gu, gv = gpu_ctx.debug_intersect(o, d)
+    ot, otri, ou, ov, _ = oracle.intersect(sc, o, d)
+    assert (ot > 0).mean() > 0.3 and (scale > 1).mean() > 0.5
+    assert np.array_equal(gtri, otri), f"{(gtri != otri).sum()} triangle ids differ"
+    assert_same_floats(gt, ot, "t")
+    assert_same_floats(gu, ou, "u")
+    assert_same_floats(gv, ov, "v")
+    gpu_ctx.set_options(cull=1, traversal=native.TRAVERSAL_AUTO)
+
+
 @pytest.mark.parametrize("name", ["cornell", "feature_box", "cornell_spheres"])
 @pytest.mark.parametrize("keep", [0, 1])
 @pytest.mark.parametrize("trav", [0, 1])       # auto (LDS for these scenes) and global: there the irregular lanes read the

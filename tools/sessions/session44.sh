@@ -4,7 +4,7 @@
 # run of this session: 4 + 116 tests)
 set -o pipefail
 out=gpurun_out/s44; mkdir -p $out
-timeout -k 10 900 python -m pytest tests/test_gpu_math.py tests/test_gpu_parity.py tests/test_gpu_full_size.py -m gpu -x -q > $out/pytest.log 2>&1; rc=$?; tail -3 $out/pytest.log; [ $rc = 0 ] || exit $rc
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $out/pytest.log 2>&1; rc=$?; tail -3 $out/pytest.log; [ $rc = 0 ] || exit $rc
 run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-cpu-baseline "$@" > $out/$tag.json 2> $out/$tag.err || exit 1; python -c "
 import json; d=json.load(open('$out/$tag.json')); print('$tag', d['value'], d['kernel_ms_rank0'], d['gpu_ms_rank0'])"; }
 ab=$PWD/wgpu-path-tracing_amd/lib/ab

@@ -41,6 +41,9 @@ struct DevScene {
     // (per leaf: exact box + first triangle + count, then 9 dwords per triangle).
     const uint4 *qnodes;        const uint32_t *leaf_stream;
     float q_origin[3], q_scale[3];
+    // |dx| + |dy| + |dz| of a ray up to which |e1 . (d x e2)| <= 2^100 for every triangle (2^98 / longest edge squared; 0 when an
+    // edge is not finite): such rays take the triangle test whose short reciprocal has no range test (pt_math.h)
+    float tri_safe_dsum;
     uint32_t q_cached;          // the first q_cached quantised nodes are the top levels in breadth-first order (kept in LDS)
 };
 

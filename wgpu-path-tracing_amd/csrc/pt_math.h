@@ -183,10 +183,13 @@ PT_DEV uint32_t f2u(float f) {
 // triggers an early return there, and fails the final t > EPSILON here as there). e1 = v1 - v0, e2 = v2 - v0.
 // Used by the traversal kernels for every candidate and by `shade` to rebuild (u, v) of the closest hit from its
 // triangle (the hit record carries only t and the triangle): same function, same operands, same bits.
-PT_DEV float tri_test(v3 v0, v3 e1, v3 e2, v3 o, v3 d, float &uo, float &vo) {
+// BOUNDED: the caller knows |a| <= 2^100 for this ray and every triangle of the scene (traverse.hip: DevScene::tri_safe_dsum),
+// so the short reciprocal needs no range test — the triangle loop stays one basic block. Same bits either way.
+template <bool BOUNDED>
+PT_DEV float tri_test_t(v3 v0, v3 e1, v3 e2, v3 o, v3 d, float &uo, float &vo) {
     v3 h = cross3(d, e2);
     float a = dot3(e1, h);
-    float f = rcp1_above_eps(a);       // |a| < PT_EPS is rejected below whatever f is
+    float f = (BOUNDED && !PT_IEEE_EXPANSIONS) ? rcp_short(a) : rcp1_above_eps(a);       // |a| < PT_EPS is rejected below whatever f is
     v3 sv = sub3(o, v0);
     float u = f * dot3(sv, h);
     v3 q = cross3(sv, e1);
@@ -197,6 +200,7 @@ PT_DEV float tri_test(v3 v0, v3 e1, v3 e2, v3 o, v3 d, float &uo, float &vo) {
     uo = u; vo = v;
     return ok ? t : -1.0f;
 }
+PT_DEV float tri_test(v3 v0, v3 e1, v3 e2, v3 o, v3 d, float &uo, float &vo) { return tri_test_t<false>(v0, e1, e2, o, d, uo, vo); }
 
 // ---- RNG: src/shader/random.wgsl:3-16 ---------------------------------------
 PT_DEV uint32_t rng_seed(uint32_t x, uint32_t y, uint32_t frame) { return x + y * 1000u + frame * 100000u; }

@@ -201,6 +201,7 @@ struct Built {
     uint32_t root_ref = PT_REF_NONE, depth = 0;
     uint32_t fast_root = PT_REF_NONE, fast_depth = 0;
     double tree_ms = 0.0;                    // time spent in pt_build_fast_tree
+    float tri_safe_dsum = 0.0f;              // DevScene::tri_safe_dsum
     std::vector<uint4> qnodes; std::vector<uint32_t> leaf_stream;     // quantised image (empty: none)
     float q_origin[3] = {0, 0, 0}, q_scale[3] = {0, 0, 0};
     uint32_t q_top = 0;                      // quantised nodes numbered breadth-first at the front (LDS-resident in the kernel)
@@ -299,6 +300,17 @@ int build_image(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_
         b.tripos[3 * (size_t)i + 0] = make_float4(t.v0[0], t.v0[1], t.v0[2], 0.0f);
         b.tripos[3 * (size_t)i + 1] = make_float4(t.v1[0] - t.v0[0], t.v1[1] - t.v0[1], t.v1[2] - t.v0[2], 0.0f);
         b.tripos[3 * (size_t)i + 2] = make_float4(t.v2[0] - t.v0[0], t.v2[1] - t.v0[1], t.v2[2] - t.v0[2], 0.0f);
+    }
+    {   // longest edge squared, in double; NaN / inf edges give 0 (no ray is "bounded" then)
+        double emax2 = 0.0; bool finite = true;
+        for (size_t k = 0; k < b.tripos.size(); k++) {
+            if (k % 3 == 0) continue;
+            const float4 &e = b.tripos[k];
+            const double l2 = (double)e.x * e.x + (double)e.y * e.y + (double)e.z * e.z;
+            if (!(l2 <= 1.7e308)) finite = false; else if (l2 > emax2) emax2 = l2;
+        }
+        const double k = !finite ? 0.0 : (emax2 > 0.0 ? std::ldexp(1.0, 98) / emax2 : 3.0e38);
+        b.tri_safe_dsum = (float)(k < 3.0e38 ? k : 3.0e38);
     }
     {
         const auto t0 = std::chrono::steady_clock::now();
@@ -507,6 +519,7 @@ int ptmi_upload_scene(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const
     s.qnodes = c->d_qnodes; s.leaf_stream = c->d_leaf_stream;
     for (int k = 0; k < 3; k++) { s.q_origin[k] = b.q_origin[k]; s.q_scale[k] = b.q_scale[k]; }
     s.q_cached = b.q_top;
+    s.tri_safe_dsum = b.tri_safe_dsum;
     for (int k = 0; k < 3; k++) { s.root_min[k] = b.root_min[k]; s.root_max[k] = b.root_max[k]; }
     s.root_ref = fast ? b.fast_root : b.root_ref;
     c->bvh_depth = std::max(b.depth, b.fast_depth);           // stacks must hold either tree (irregular rays use the uploaded one)

@@ -315,7 +315,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
     const uint32_t ngroups = (count + 63u) >> 6;
     const uint32_t end = gw < ngroups ? ((ngroups - gw + total_waves - 1u) / total_waves) * 64u : 0u;
     uint32_t next = 0u;
-    bool active = false, use_ref = false;
+    bool active = false, use_ref = false, unbounded = false;
     uint32_t slot = 0, cur = PT_REF_NONE;
     // this lane's LDS entries as two pointers: the node stack grows up from `bot` (sp = next free entry), the list
     // of filed leaves grows down from `top` (lp = next free entry); STACK - used = (lp - sp) / stride + 1 entries free
@@ -347,6 +347,8 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                 const bool regular = __builtin_isfinite(inv.x) & __builtin_isfinite(inv.y) & __builtin_isfinite(inv.z) &
                                      (inv.x != 0.0f) & (inv.y != 0.0f) & (inv.z != 0.0f) & Mem::in_range(o, inv);
                 use_ref = sc.has_fast != 0u && !regular;
+                // the triangle test's determinant stays below 2^100 for this ray (NaN compares false): pt_math.h tri_test_t
+                unbounded = !((__builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z)) <= sc.tri_safe_dsum);
                 m.prep(o, inv, rk);
                 float tm;
                 if (want && sc.root_ref != PT_REF_NONE &&
@@ -375,7 +377,9 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
         bool occluded = false;
         // Two copies of the streams: lanes that walk the uploaded tree (irregular rays, use_ref) read it from global memory
         // in its own format; a wave holds such a lane almost never, and every other time it runs the copy without that
-        // per-step choice.
+        // per-step choice. The same copy serves rays whose triangle-test determinant is not known to stay below 2^100 (`unbounded`:
+        // direction components summing to more than DevScene::tri_safe_dsum — none in a dispatch, whose directions are unit
+        // vectors, unless the scene has edges longer than 2^49): it keeps the range test of the short reciprocal, the other drops it.
         auto streams = [&](auto with_ref) {
         constexpr bool REF = decltype(with_ref)::value;
         const bool old = REF && use_ref;
@@ -394,7 +398,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                         float4 a, b, c;
                         m.tri(cursor, k, plain, a, b, c);
                         float u = 0.0f, v = 0.0f;
-                        const float t = tri_test(xyz(a), xyz(b), xyz(c), o, d, u, v);
+                        const float t = tri_test_t<!REF>(xyz(a), xyz(b), xyz(c), o, d, u, v);
                         const bool hit = t > 0.0f;
                         const uint32_t ti = first + k;
                         if (ANY) {
@@ -464,7 +468,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
             }
         }
         };
-        if (sc.has_fast != 0u && ballot(use_ref & active) != 0ull) streams(std::true_type{});
+        if (ballot((use_ref | unbounded) & active) != 0ull) streams(std::true_type{});
         else streams(std::false_type{});
         // hang guard: an active lane that can take neither stream (cannot happen while STACK > tree depth) ends here
         const bool stuck = active & !can_node & !can_tri & ((bn | bt) == 0ull);
