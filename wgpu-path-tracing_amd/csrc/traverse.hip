@@ -315,7 +315,8 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
     const uint32_t ngroups = (count + 63u) >> 6;
     const uint32_t end = gw < ngroups ? ((ngroups - gw + total_waves - 1u) / total_waves) * 64u : 0u;
     uint32_t next = 0u;
-    bool active = false, use_ref = false, unbounded = false;
+    bool active = false, slow = false;      // slow: an irregular ray or an unbounded determinant, see the refill
+    const bool has_fast = sc.has_fast != 0u;
     uint32_t slot = 0, cur = PT_REF_NONE;
     // this lane's LDS entries as two pointers: the node stack grows up from `bot` (sp = next free entry), the list
     // of filed leaves grows down from `top` (lp = next free entry); STACK - used = (lp - sp) / stride + 1 entries free
@@ -346,16 +347,19 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                 limit = (ANY && CULL) ? cull_limit(tlim) : __builtin_inff();      // NaN for a directional light: never culls
                 const bool regular = __builtin_isfinite(inv.x) & __builtin_isfinite(inv.y) & __builtin_isfinite(inv.z) &
                                      (inv.x != 0.0f) & (inv.y != 0.0f) & (inv.z != 0.0f) & Mem::in_range(o, inv);
-                use_ref = sc.has_fast != 0u && !regular;
-                // the triangle test's determinant stays below 2^100 for this ray (NaN compares false): pt_math.h tri_test_t
-                unbounded = !((__builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z)) <= sc.tri_safe_dsum);
+                // bounded: the triangle test's determinant stays below 2^100 for this ray (NaN compares false): pt_math.h tri_test_t.
+                // ONE flag for both kinds of special ray (a second wave-wide mask would take the kernel's scalar registers past 80
+                // and with them the second workgroup per CU): they run the careful copy of the streams below, and where the
+                // hierarchy was rebuilt they walk the tree as uploaded.
+                const bool bounded = (__builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z)) <= sc.tri_safe_dsum;
+                slow = !(regular & bounded);
                 m.prep(o, inv, rk);
                 float tm;
                 if (want && sc.root_ref != PT_REF_NONE &&
                     slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2],
                          o, inv, tm)) {
                     active = true;
-                    const uint32_t r = use_ref ? sc.ref_root_ref : sc.root_ref;
+                    const uint32_t r = (has_fast & slow) ? sc.ref_root_ref : sc.root_ref;
                     if (r & PT_REF_LEAF) { *lp = r; lp -= stride; }              // a one-leaf tree: file the root
                     else cur = r;
                 } else {
@@ -377,12 +381,12 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
         bool occluded = false;
         // Two copies of the streams: lanes that walk the uploaded tree (irregular rays, use_ref) read it from global memory
         // in its own format; a wave holds such a lane almost never, and every other time it runs the copy without that
-        // per-step choice. The same copy serves rays whose triangle-test determinant is not known to stay below 2^100 (`unbounded`:
+        // per-step choice. The same copy serves rays whose triangle-test determinant is not known to stay below 2^100 (not `bounded`:
         // direction components summing to more than DevScene::tri_safe_dsum — none in a dispatch, whose directions are unit
         // vectors, unless the scene has edges longer than 2^49): it keeps the range test of the short reciprocal, the other drops it.
         auto streams = [&](auto with_ref) {
         constexpr bool REF = decltype(with_ref)::value;
-        const bool old = REF && use_ref;
+        const bool old = REF && has_fast && slow;
         if (run_tri) {
             bool ct = can_tri;
 #pragma unroll 1
@@ -429,7 +433,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                     float tl, tr;
                     bool hl, hr;
                     uint32_t lref, rref;
-                    if (REF && use_ref) {
+                    if (REF && has_fast && slow) {
                         float4 a, b, c, r;
                         load_node((glb_f4p)sc.ref_wnodes + 4u * (size_t)cur, a, b, c, r);
                         Boxes nb; boxes_of(a, b, c, r, nb);
@@ -468,7 +472,7 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
             }
         }
         };
-        if (ballot((use_ref | unbounded) & active) != 0ull) streams(std::true_type{});
+        if (ballot(slow & active) != 0ull) streams(std::true_type{});
         else streams(std::false_type{});
         // hang guard: an active lane that can take neither stream (cannot happen while STACK > tree depth) ends here
         const bool stuck = active & !can_node & !can_tri & ((bn | bt) == 0ull);
