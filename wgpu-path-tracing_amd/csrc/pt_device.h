@@ -74,7 +74,9 @@ struct DevPaths {
 // shadow record, 44 B per queue slot:
 //   SO = (origin.xyz, dist or -1 for directional)  SD = (wi.xyz, bits(path id))
 //   SC = throughput * directLight .xyz (12-byte stride)   added to L[path] when unoccluded
-struct DevShadow { float4 *SO, *SD; rgb_sc *SC; };   // 44 B per queue slot
+// One allocation per bounce parity: SO at the base, SD `cap` float4 further, SC after both (the shadow kernel carries only the
+// base and cap: two pointers fewer in scalar registers, see traverse.hip ShadowIO)
+struct DevShadow { float4 *SO, *SD; rgb_sc *SC; uint32_t cap; };   // 44 B per queue slot
 
 // The rows one context renders: [y0, y1) of a width x height frame, or — when parts > 1 — every parts-th strip
 // of `strip` rows inside that range, starting with strip number `part` (row bands interleaved across GPUs so each

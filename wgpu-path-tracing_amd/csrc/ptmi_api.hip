@@ -154,7 +154,7 @@ struct Timed {
 void free_batch(Lane &ln) {
     dfree(ln.paths.O); dfree(ln.paths.D); dfree(ln.paths.C); dfree(ln.paths.L);
     dfree(ln.hits);
-    for (int k = 0; k < 2; k++) { dfree(ln.sh[k].SO); dfree(ln.sh[k].SD); dfree(ln.sh[k].SC); dfree(ln.sq[k]); }
+    for (int k = 0; k < 2; k++) { dfree(ln.sh[k].SO); ln.sh[k].SD = nullptr; ln.sh[k].SC = nullptr; dfree(ln.sq[k]); }
     dfree(ln.queue[0]); dfree(ln.queue[1]); dfree(ln.alive); dfree(ln.shadowm); dfree(ln.octm); dfree(ln.word_off); dfree(ln.d_occ);
     ln.cap = 0;
 }
@@ -181,8 +181,9 @@ int ensure_capacity(ptmi_ctx *c, Lane &ln, size_t n) {
     HIP_TRY(c, hipMalloc(&ln.paths.C, cap * 8)); HIP_TRY(c, hipMalloc(&ln.paths.L, cap * 16));      // room for either stride
     HIP_TRY(c, hipMalloc(&ln.hits, cap * 8));
     for (int k = 0; k < 2; k++) {
-        HIP_TRY(c, hipMalloc(&ln.sh[k].SO, cap * 16)); HIP_TRY(c, hipMalloc(&ln.sh[k].SD, cap * 16));
-        HIP_TRY(c, hipMalloc(&ln.sh[k].SC, cap * sizeof(rgb_sc))); HIP_TRY(c, hipMalloc(&ln.sq[k], cap * 4));
+        HIP_TRY(c, hipMalloc(&ln.sh[k].SO, cap * (16 + 16 + sizeof(rgb_sc))));
+        ln.sh[k].SD = ln.sh[k].SO + cap; ln.sh[k].SC = reinterpret_cast<rgb_sc *>(ln.sh[k].SO + 2 * cap); ln.sh[k].cap = (uint32_t)cap;
+        HIP_TRY(c, hipMalloc(&ln.sq[k], cap * 4));
     }
     HIP_TRY(c, hipMalloc(&ln.queue[0], cap * 4)); HIP_TRY(c, hipMalloc(&ln.queue[1], cap * 4));
     HIP_TRY(c, hipMalloc(&ln.alive, words * 8)); HIP_TRY(c, hipMalloc(&ln.shadowm, words * 8));
@@ -345,7 +346,10 @@ TraverseConfig traverse_config(const ptmi_ctx *c, bool closest_hit) {
     cfg.quantized = c->opt.traversal == PTMI_TRAVERSAL_GLOBAL ||
                     (c->opt.traversal == PTMI_TRAVERSAL_AUTO && c->lds_scene_bytes > ((size_t)4 << 20));
     if (c->opt.traversal == PTMI_TRAVERSAL_GLOBAL || c->opt.traversal == PTMI_TRAVERSAL_GLOBAL_EXACT) cfg.variant = PT_VARIANT_GLOBAL;
-    else if (closest_hit && node_cache && c->opt.traversal == PTMI_TRAVERSAL_AUTO) {   // any-hit: measured 15 % slower with it
+#ifndef PT_SHADOW_NODE_CACHE
+#define PT_SHADOW_NODE_CACHE 0
+#endif
+    else if ((closest_hit || PT_SHADOW_NODE_CACHE) && node_cache && c->opt.traversal == PTMI_TRAVERSAL_AUTO) {   // any-hit: measured 15 % slower with it
         cfg.variant = PT_VARIANT_LDS_NODES; cfg.stack_entries = small_stack;
     } else if (fits) { cfg.variant = PT_VARIANT_LDS; cfg.stack_entries = lds_stack; }
     else if (have && closest_hit && c->opt.traversal == PTMI_TRAVERSAL_AUTO &&

@@ -259,13 +259,16 @@ struct ExtendIO {
     }
     PT_DEV void finish(uint32_t slot, const Hit &h, bool) const { st_stream(&hits[slot], pack_hit(h)); }
 };
+// The records of a bounce are one allocation (pt_device.h DevShadow): the kernel keeps its base and `cap` instead of three
+// pointers, and the radiance buffer instead of the whole path state — the node-cache variant needs at most 80 scalar
+// registers for its two workgroups per CU.
 struct ShadowIO {
-    DevPaths P; DevShadow S; const uint32_t *sq; uint8_t *occluded_out;
+    float *L; const float4 *rec; const uint32_t *sq; uint32_t l_stride, cap;
     // false: nothing to trace — the record of an emissive hit (SO.w = -2, shade.hip), added to L like an unoccluded sample
     PT_DEV bool fetch(uint32_t &slot, v3 &o, v3 &d, float &tlim) const {
         uint32_t i = sq ? sq[slot] : slot;
         slot = i;                                              // the record's own slot is what finish() needs
-        float4 so = ld_stream(&S.SO[i]), sd = ld_stream(&S.SD[i]);
+        float4 so = ld_stream(&rec[i]), sd = ld_stream(&rec[(size_t)cap + i]);
         o = xyz(so); d = xyz(sd);
         // pt.wgsl:423, :465: occluded iff a hit is nearer than dist - 2e-6 (negative for a light closer than 2e-6: never
         // occluded). A directional light (:394) has no distance, any hit occludes, one at t = +inf included: tlim = NaN,
@@ -274,13 +277,22 @@ struct ShadowIO {
         return so.w != -2.0f;
     }
     PT_DEV void finish(uint32_t i, const Hit &, bool occluded) const {
-        if (occluded_out) { occluded_out[i] = occluded ? 1 : 0; return; }
         if (!occluded) {
-            uint32_t p = __float_as_uint(S.SD[i].w);
-            const rgb_sc l = P.ldL(p), c = S.SC[i];
+            const uint32_t p = __float_as_uint(rec[(size_t)cap + i].w);
+            DevPaths P; P.O = nullptr; P.D = nullptr; P.C = nullptr; P.L = L; P.l_stride = l_stride;
+            const rgb_sc l = P.ldL(p), c = reinterpret_cast<const rgb_sc *>(rec + 2 * (size_t)cap)[i];
             P.stL(p, l.x + c.x, l.y + c.y, l.z + c.z);   // pt.wgsl:675
         }
     }
+};
+// ptmi_debug_occluded: the same rays, the verdict written out instead of added
+struct OccludedIO {
+    const float4 *rec; uint8_t *occluded_out; uint32_t cap;
+    PT_DEV bool fetch(uint32_t &slot, v3 &o, v3 &d, float &tlim) const {
+        ShadowIO s{nullptr, rec, nullptr, 3u, cap};
+        return s.fetch(slot, o, d, tlim);
+    }
+    PT_DEV void finish(uint32_t i, const Hit &, bool occluded) const { occluded_out[i] = occluded ? 1 : 0; }
 };
 
 // One wave traces the 64-slot groups gw, gw + total_waves, gw + 2 total_waves, ... of a queue of
@@ -625,7 +637,13 @@ void pt_launch_extend(hipStream_t s, int blocks, const TraverseConfig &cfg, cons
 
 void pt_launch_shadow(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, DevPaths p,
                       DevShadow sh, const uint32_t *shadow_queue, const uint32_t *count, uint8_t *occ) {
-    ShadowIO io{p, sh, shadow_queue, occ};
+    if (occ) {                                  // ptmi_debug_occluded (never with a queue)
+        OccludedIO io{sh.SO, occ, sh.cap};
+        if (cfg.cull) launch<MODE_SHADOW, true>(s, blocks, cfg, sc, io, count);
+        else launch<MODE_SHADOW, false>(s, blocks, cfg, sc, io, count);
+        return;
+    }
+    ShadowIO io{p.L, sh.SO, shadow_queue, p.l_stride, sh.cap};
     if (cfg.cull) launch<MODE_SHADOW, true>(s, blocks, cfg, sc, io, count);
     else launch<MODE_SHADOW, false>(s, blocks, cfg, sc, io, count);
 }
