@@ -615,8 +615,12 @@ void launch(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene
         launch_lds<MODE, CULL, 16, false, true>(s, cus, bytes, sc, io, count, cfg.spill);
     } else if (cfg.variant == PT_VARIANT_LDS_NODES) {          // node cache, two workgroups per CU
         const size_t bytes = (size_t)sc.n_wnodes * 64 + stack_bytes;
-        if (cfg.stack_entries <= 15) launch_lds<MODE, CULL, 15, false>(s, 2 * cus, bytes, sc, io, count);
-        else launch_lds<MODE, CULL, 16, false>(s, 2 * cus, bytes, sc, io, count);
+#ifndef PT_SHADOW_NODE_CACHE_WGS
+#define PT_SHADOW_NODE_CACHE_WGS 2
+#endif
+        const int wgs = (MODE == MODE_SHADOW ? PT_SHADOW_NODE_CACHE_WGS : 2) * cus;
+        if (cfg.stack_entries <= 15) launch_lds<MODE, CULL, 15, false>(s, wgs, bytes, sc, io, count);
+        else launch_lds<MODE, CULL, 16, false>(s, wgs, bytes, sc, io, count);
     } else if (cfg.variant == PT_VARIANT_LDS) {                // everything resident, one workgroup per CU
         const size_t bytes = cfg.lds_scene_bytes + stack_bytes;
         if (cfg.stack_entries <= 16) launch_lds<MODE, CULL, 16, true>(s, cus, bytes, sc, io, count);
