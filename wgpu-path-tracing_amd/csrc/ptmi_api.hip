@@ -349,7 +349,10 @@ TraverseConfig traverse_config(const ptmi_ctx *c, bool closest_hit) {
 #ifndef PT_SHADOW_NODE_CACHE
 #define PT_SHADOW_NODE_CACHE 0
 #endif
-    else if ((closest_hit || PT_SHADOW_NODE_CACHE) && node_cache && c->opt.traversal == PTMI_TRAVERSAL_AUTO) {   // any-hit: measured 15 % slower with it
+    // The any-hit kernel keeps the full LDS image, one workgroup per CU. From the node cache with two workgroups (80 scalar
+    // registers since round 2) it is as fast by itself (8.53 ms per 64 spp either way) but takes every wave slot of its CUs: beside it
+    // `shade` stretches from 16.5 to 18.3 ms and config 1 loses 4 % (9 767 -> 9 344); with one workgroup it is 40 % slower itself.
+    else if ((closest_hit || PT_SHADOW_NODE_CACHE) && node_cache && c->opt.traversal == PTMI_TRAVERSAL_AUTO) {
         cfg.variant = PT_VARIANT_LDS_NODES; cfg.stack_entries = small_stack;
     } else if (fits) { cfg.variant = PT_VARIANT_LDS; cfg.stack_entries = lds_stack; }
     else if (have && closest_hit && c->opt.traversal == PTMI_TRAVERSAL_AUTO &&
