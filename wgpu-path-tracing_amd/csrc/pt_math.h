@@ -132,7 +132,17 @@ PT_DEV v3 lincomb3(v3 a, float s1, v3 b, float s2, v3 c, float s3) {
 // WGSL vector / scalar: one IEEE reciprocal, three multiplies
 PT_DEV v3 vdiv3(v3 a, float s) { float inv = rcp1(s); return mk3(a.x * inv, a.y * inv, a.z * inv); }
 PT_DEV float length3(v3 a) { return sqrt1(dot3(a, a)); }
-PT_DEV v3 normalize3(v3 a) { return vdiv3(a, length3(a)); }
+// a / sqrt(a.a): one range test covers both short forms (a.a within [2^-100, 2^100] puts its root within [2^-50, 2^50])
+PT_DEV v3 normalize3(v3 a) {
+#if PT_IEEE_EXPANSIONS
+    return vdiv3(a, length3(a));
+#else
+    const float l2 = dot3(a, a);
+    float inv = rcp_short(sqrt_short(l2));
+    if (__builtin_expect(!((l2 >= 0x1p-100f) & (l2 <= 0x1p100f)), 0)) inv = 1.0f / __builtin_sqrtf(l2);
+    return mk3(a.x * inv, a.y * inv, a.z * inv);
+#endif
+}
 PT_DEV float mix1(float a, float b, float t) { return fma1(b, t, a * (1.0f - t)); }
 PT_DEV v3 reflect3(v3 i, v3 n) {
     float k = 2.0f * dot3(n, i);
