@@ -701,7 +701,9 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
                                     ln.word_off, ln.queue[cur ^ 1], &ln.counts[b + 1], ln.sq[par], &ln.counts[kShadowCount + par],
                                     c->d_stats, b, last ? 0 : 1, octm, (uint32_t)ln.mask_words); }
                 if (two_lanes && b == mid_bounce) { HIP_TRY(c, hipEventRecord(ln.ev_mid, ms)); ln.mid_recorded = true; }
-                if (side && !(gated && !last)) {
+                if (gated && !last) {
+                    // launched after the next bounce's extend, above
+                } else if (side) {
                     HIP_TRY(c, hipEventRecord(ln.ev_ready, ms));
                     HIP_TRY(c, hipStreamWaitEvent(ss, ln.ev_ready, 0));
                     { Timed t(c, 3, t3, ss);
