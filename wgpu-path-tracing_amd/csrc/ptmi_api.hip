@@ -576,7 +576,7 @@ int ptmi_set_options(ptmi_ctx *c, const ptmi_options *o) {
         return fail(c, PTMI_E_INVALID, "tile_part %u is not below tile_parts %u", o->tile_part, o->tile_parts);
     if (o->perf_mode > 1) return fail(c, PTMI_E_INVALID, "unknown perf_mode %u", o->perf_mode);
     if (o->ray_sort > 2) return fail(c, PTMI_E_INVALID, "unknown ray_sort %u", o->ray_sort);
-    if (o->overlap > 4) return fail(c, PTMI_E_INVALID, "unknown overlap %u", o->overlap);
+    if (o->overlap > 3) return fail(c, PTMI_E_INVALID, "unknown overlap %u", o->overlap);
     c->opt = *o;
     return PTMI_OK;
 }
@@ -623,9 +623,6 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     // take turns instead of sharing.
     const bool side = nee && c->opt.overlap != 0;
     const bool two_lanes = c->opt.overlap == 3 && F >= 2;
-    // overlap 4: as 1, but `shadow` of bounce b is held back until `extend` of bounce b + 1 has finished, so that it runs beside
-    // `shade` (which leaves a third of the vector ALUs idle) rather than beside `extend` (which leaves none)
-    const bool gated = side && c->opt.overlap == 4;
     const uint32_t Fsub = two_lanes ? (F + 1) / 2 : F;              // frames per traced batch
     if (npix * Fsub > 0xFFFFFF00ull) return fail(c, PTMI_E_UNSUPPORTED, "batch of %llu paths exceeds 2^32", (unsigned long long)(npix * Fsub));
     const TraverseConfig cfg0 = traverse_config(c, true), cfg_shadow0 = traverse_config(c, false);
@@ -682,14 +679,6 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
                 const int par = side ? (int)(b & 1u) : 0;
                 { Timed t(c, 1, t2, ms); pt_launch_extend(ms, blocks, cfg, c->sc, ln.paths, q, &ln.counts[b], ln.hits); }
                 const bool last = b + 1 == maxb;
-                if (gated && b >= 1) {                  // the held-back shadow kernel of bounce b - 1
-                    const int pp = (int)((b - 1u) & 1u);
-                    HIP_TRY(c, hipEventRecord(ln.ev_ready, ms));
-                    HIP_TRY(c, hipStreamWaitEvent(ss, ln.ev_ready, 0));
-                    { Timed t(c, 3, t3, ss);
-                      pt_launch_shadow(ss, blocks, cfg_shadow, c->sc, ln.paths, ln.sh[pp], ln.sq[pp], &ln.counts[kShadowCount + pp], nullptr); }
-                    HIP_TRY(c, hipEventRecord(ln.ev_shadow[pp], ss));
-                }
                 uint64_t *octm = (sort && !last) ? ln.octm : nullptr;
                 if (side && b >= 2) HIP_TRY(c, hipStreamWaitEvent(ms, ln.ev_shadow[par], 0));      // its records are read
                 { Timed t(c, 2, t3, ms);
@@ -701,9 +690,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
                                     ln.word_off, ln.queue[cur ^ 1], &ln.counts[b + 1], ln.sq[par], &ln.counts[kShadowCount + par],
                                     c->d_stats, b, last ? 0 : 1, octm, (uint32_t)ln.mask_words); }
                 if (two_lanes && b == mid_bounce) { HIP_TRY(c, hipEventRecord(ln.ev_mid, ms)); ln.mid_recorded = true; }
-                if (gated && !last) {
-                    // launched after the next bounce's extend, above
-                } else if (side) {
+                if (side) {
                     HIP_TRY(c, hipEventRecord(ln.ev_ready, ms));
                     HIP_TRY(c, hipStreamWaitEvent(ss, ln.ev_ready, 0));
                     { Timed t(c, 3, t3, ss);
