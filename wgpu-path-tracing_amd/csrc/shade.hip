@@ -293,27 +293,13 @@ __global__ __launch_bounds__(SBLOCK) PT_SHADE_ATTR void k_shade(DevScene sc, Dev
                                                   uint64_t *__restrict__ shadow_mask, ShadeParams sp) {
     const uint32_t count = *count_ptr;
     uint32_t n_skipped = 0, n_emitted = 0;  // lane 0 of each wave: one atomic per wave at the end
-    // The first link of the chain of dependent loads — queue entry and hit record — is fetched one iteration ahead.
-#ifndef PT_SHADE_PREFETCH
-#define PT_SHADE_PREFETCH 1
-#endif
-    uint32_t p_next = 0; float2 h_next = make_float2(-1.0f, 0.0f);
-    if (PT_SHADE_PREFETCH) {
-        const uint32_t i0 = blockIdx.x * SBLOCK + threadIdx.x;
-        if (i0 < count) { p_next = queue ? queue[i0] : i0; h_next = ld_stream(&hits[i0]); }
-    }
     for (uint32_t base = blockIdx.x * SBLOCK; base < count; base += gridDim.x * SBLOCK) {
         const uint32_t i = base + threadIdx.x;
         bool alive = false, shadow = false, skipped = false, emitted = false;
         bool neg_x = false, neg_y = false, neg_z = false;          // ray_sort: octant of the new direction
-        uint32_t p_cur = p_next; float2 h_cur = h_next;
-        if (PT_SHADE_PREFETCH) {
-            const uint32_t in = i + gridDim.x * SBLOCK;
-            if (in < count) { p_next = queue ? queue[in] : in; h_next = ld_stream(&hits[in]); }
-        }
         if (i < count) {
-            const uint32_t p = PT_SHADE_PREFETCH ? p_cur : (queue ? queue[i] : i);
-            const float2 h2 = PT_SHADE_PREFETCH ? h_cur : ld_stream(&hits[i]);
+            const uint32_t p = queue ? queue[i] : i;
+            const float2 h2 = ld_stream(&hits[i]);
             if (!(h2.x < 0.0f)) {                                            // pt.wgsl:646: miss adds zero
                 const float4 o4 = ld_stream(&P.O[p]), d4 = ld_stream(&P.D[p]);
                 uint32_t rng = __float_as_uint(o4.w);
