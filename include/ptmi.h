@@ -82,8 +82,7 @@ typedef struct ptmi_options {
                                    second started when the first has finished bounce 3, so that a half's last bounces run beside
                                    the next half's first ones; the halves are folded into the output in frame order on the
                                    context's stream (same bits; measured slower than 1, kept for
-                                   experiments); 5: whole batches alternate between the two lanes, the next started when this one has
-                                   compacted its last bounce but one (twice the path state). 2 = library default (currently 1) */
+                                   experiments). 2 = library default (currently 1) */
     uint32_t reserved[1];
 } ptmi_options;
 

@@ -576,7 +576,7 @@ int ptmi_set_options(ptmi_ctx *c, const ptmi_options *o) {
         return fail(c, PTMI_E_INVALID, "tile_part %u is not below tile_parts %u", o->tile_part, o->tile_parts);
     if (o->perf_mode > 1) return fail(c, PTMI_E_INVALID, "unknown perf_mode %u", o->perf_mode);
     if (o->ray_sort > 2) return fail(c, PTMI_E_INVALID, "unknown ray_sort %u", o->ray_sort);
-    if (o->overlap > 5 || o->overlap == 4) return fail(c, PTMI_E_INVALID, "unknown overlap %u", o->overlap);
+    if (o->overlap > 3) return fail(c, PTMI_E_INVALID, "unknown overlap %u", o->overlap);
     c->opt = *o;
     return PTMI_OK;
 }
@@ -622,12 +622,8 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     // 10 - 12 % SLOWER on every config (profiles/README.md): two persistent traversal grids, each sized to own every CU's LDS,
     // take turns instead of sharing.
     const bool side = nee && c->opt.overlap != 0;
-    // overlap 5: whole batches alternate between the two lanes (no halving), the next one started when this one has compacted its
-    // last bounce but one — across batches of a dispatch and across dispatches: only a batch's last two bounces, its last shadow
-    // kernels and its fold run beside the next batch's first kernels.
-    const bool whole = c->opt.overlap == 5;
-    const bool two_lanes = (c->opt.overlap == 3 && F >= 2) || whole;
-    const uint32_t Fsub = (two_lanes && !whole) ? (F + 1) / 2 : F;              // frames per traced batch
+    const bool two_lanes = c->opt.overlap == 3 && F >= 2;
+    const uint32_t Fsub = two_lanes ? (F + 1) / 2 : F;              // frames per traced batch
     if (npix * Fsub > 0xFFFFFF00ull) return fail(c, PTMI_E_UNSUPPORTED, "batch of %llu paths exceeds 2^32", (unsigned long long)(npix * Fsub));
     const TraverseConfig cfg0 = traverse_config(c, true), cfg_shadow0 = traverse_config(c, false);
     if (c->opt.traversal == PTMI_TRAVERSAL_LDS && cfg0.variant != PT_VARIANT_LDS)
@@ -677,7 +673,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
             }
             { Timed t(c, 4, t3, ms); pt_launch_raygen(ms, blocks, *cam, band, frame0, fb, ln.paths, &ln.counts[0]); }
             int cur = 0;
-            const uint32_t mid_bounce = whole ? (maxb >= 2u ? maxb - 2u : 0u) : std::min(3u, maxb - 1u);
+            const uint32_t mid_bounce = std::min(3u, maxb - 1u);
             for (uint32_t b = 0; b < maxb; b++) {
                 const uint32_t *q = b == 0 ? nullptr : ln.queue[cur];      // bounce 0: slot i holds path i
                 const int par = side ? (int)(b & 1u) : 0;
