@@ -54,9 +54,7 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(ptmi_camera cam, DevBand band,
     if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = total;
     for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < total; p += gridDim.x * BLOCK) {
         uint32_t k = p / npix, pix = p - k * npix;
-        uint32_t lrow, x;
-        band.pixel_of(pix, lrow, x);
-        const uint32_t y = band.row_of(lrow);
+        uint32_t y = band.row_of(pix / band.width), x = pix % band.width;
         v3 o, d; uint32_t rng;
         camera_ray(cam, x, y, frame0 + k, o, d, rng);
         init_path(P, p, o, d, rng);
@@ -282,9 +280,7 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(DevBand band, uint32_t fra
                                                       const float *__restrict__ L, uint32_t l_stride, float4 *__restrict__ out) {
     const uint32_t npix = band.rows * band.width;
     for (uint32_t pix = blockIdx.x * BLOCK + threadIdx.x; pix < npix; pix += gridDim.x * BLOCK) {
-        uint32_t lrow, x;
-        band.pixel_of(pix, lrow, x);
-        const size_t oi = (size_t)band.row_of(lrow) * band.width + x;
+        const size_t oi = (size_t)band.row_of(pix / band.width) * band.width + pix % band.width;
         float4 acc = out[oi];
         for (uint32_t k = 0; k < n_frames; k++) {
             const size_t li = (size_t)k * npix + pix;

@@ -87,19 +87,6 @@ struct DevBand {
         if (parts <= 1u) return y0 + l;
         return y0 + ((l / strip) * parts + part) * strip + l % strip;
     }
-    // Pixel number within the band -> (local row, x). Where the band is a whole number of 16 x 4 tiles, 64 consecutive numbers are
-    // one tile rather than a 64 x 1 strip of a row: a wave's camera rays then stay together through the first levels of the tree.
-    // Path ids are only names (the RNG is seeded by x, y, frame), so the image does not depend on this.
-#ifndef PT_PIXEL_TILES
-#define PT_PIXEL_TILES 1
-#endif
-    PT_HD void pixel_of(uint32_t pix, uint32_t &lrow, uint32_t &x) const {
-        if (PT_PIXEL_TILES && (width & 15u) == 0u && (rows & 3u) == 0u) {
-            const uint32_t t = pix >> 6, w = pix & 63u, per_row = width >> 4;
-            x = (t % per_row) * 16u + (w & 15u);
-            lrow = (t / per_row) * 4u + (w >> 4);
-        } else { lrow = pix / width; x = pix % width; }
-    }
 };
 
 struct ShadeParams {
