@@ -56,19 +56,24 @@ PT_DEV v4 texture_color(const DevScene &sc, const ptmi_atlas_rect &tx, float uvx
 PT_DEV HitInfo make_hitinfo(const DevScene &sc, v3 ro, v3 rd, float t, uint32_t tri) {
     HitInfo hi;
     const ptmi_triangle &T = sc.tris[tri];
-    v3 v0 = ld3(T.v0);
-    v3 e1 = sub3(ld3(T.v1), v0), e2 = sub3(ld3(T.v2), v0);
+    // the whole triangle record is requested before the first use: the range tests of the short reciprocal / square root below
+    // are branches, and a load placed after one is not issued before it
+    const v3 tv0 = ld3(T.v0), tv1 = ld3(T.v1), tv2 = ld3(T.v2);
+    const v3 tn0 = ld3(T.n0), tn1 = ld3(T.n1), tn2 = ld3(T.n2);
+    const float u0x = T.uv0[0], u0y = T.uv0[1], u1x = T.uv1[0], u1y = T.uv1[1], u2x = T.uv2[0], u2y = T.uv2[1];
+    const uint32_t mi = T.material_index;
+    v3 v0 = tv0;
+    v3 e1 = sub3(tv1, v0), e2 = sub3(tv2, v0);
     float u, v;
     (void)tri_test(v0, e1, e2, ro, rd, u, v);
     hi.t = t;
     hi.position = madd3(rd, t, ro);
     float w = 1.0f - u - v;
     v3 geo_n = normalize3(cross3(e1, e2));
-    v3 n_i = normalize3(lincomb3(ld3(T.n0), w, ld3(T.n1), u, ld3(T.n2), v));
-    float uvx = fma1(T.uv2[0], v, fma1(T.uv1[0], u, T.uv0[0] * w));
-    float uvy = fma1(T.uv2[1], v, fma1(T.uv1[1], u, T.uv0[1] * w));
+    v3 n_i = normalize3(lincomb3(tn0, w, tn1, u, tn2, v));
+    float uvx = fma1(u2x, v, fma1(u1x, u, u0x * w));
+    float uvy = fma1(u2y, v, fma1(u1y, u, u0y * w));
     hi.is_front = dot3(geo_n, rd) < 0.0f;
-    uint32_t mi = T.material_index;
     ptmi_material m;
     if (mi < sc.n_mats) m = sc.mats[mi];
     else __builtin_memset(&m, 0, sizeof m);
@@ -86,8 +91,8 @@ PT_DEV HitInfo make_hitinfo(const DevScene &sc, v3 ro, v3 rd, float t, uint32_t 
     v4 flat; flat.x = 0.5f; flat.y = 0.5f; flat.z = 1.0f; flat.w = 1.0f;
     v4 nm = texture_color(sc, m.normal_map, uvx, uvy, flat);
     if (nm.x != 0.5f || nm.y != 0.5f || nm.z != 1.0f) {
-        float du1x = T.uv1[0] - T.uv0[0], du1y = T.uv1[1] - T.uv0[1];
-        float du2x = T.uv2[0] - T.uv0[0], du2y = T.uv2[1] - T.uv0[1];
+        float du1x = u1x - u0x, du1y = u1y - u0y;
+        float du2x = u2x - u0x, du2y = u2y - u0y;
         float rr = rcp1(fma1(du1x, du2y, -(du1y * du2x)));
         v3 tg = mk3(fma1(e1.x, du2y, -(e2.x * du1y)) * rr, fma1(e1.y, du2y, -(e2.y * du1y)) * rr,
                     fma1(e1.z, du2y, -(e2.z * du1y)) * rr);
