@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PTMI_ABI_VERSION 2
+#define PTMI_ABI_VERSION 3
 
 enum {
     PTMI_OK = 0,
@@ -83,7 +83,14 @@ typedef struct ptmi_options {
                                    the next half's first ones; the halves are folded into the output in frame order on the
                                    context's stream (same bits; measured slower than 1, kept for
                                    experiments). 2 = library default (currently 1) */
-    uint32_t reserved[1];
+    /* ABI 3 */
+    uint32_t worklist;          /* triangle tests of the LDS traversal kernels through a per-wave work list: lanes list the triangles
+                                   of the leaves they open as (ray lane, triangle) items in LDS and all 64 lanes take one item each,
+                                   the closest hit reduced with an LDS 64-bit minimum on (t bits, triangle) — the same (t, lowest
+                                   index) rule, so results are unchanged. 0 = library default, 1 = off, 2 = on where it fits */
+    uint32_t tails;             /* how the last bounces' small queues are traced: 0 = library default, 1 = every kernel its own launch,
+                                   2 = `shadow` of bounce b and `extend` of bounce b + 1 share ONE traversal launch (results unchanged) */
+    uint32_t reserved[6];
 } ptmi_options;
 
 typedef struct ptmi_stats {
@@ -111,6 +118,10 @@ typedef struct ptmi_stats {
     double   upload_ms;         /* wall time of the last ptmi_upload_scene, and its parts: validation + traversal image, */
     double   upload_tree_ms;    /* ... the hierarchy rebuilt over the uploaded leaves, */
     double   upload_copy_ms;    /* ... host-to-device copies */
+    /* ABI 3 */
+    uint32_t worklist_used;     /* of the last dispatch / per-stage call: bit 0 the closest-hit kernel, bit 1 the any-hit kernel ran the
+                                   per-wave work list (ptmi_options.worklist) */
+    uint32_t tails_used;        /* ... 1: shadow(b) and extend(b + 1) shared one traversal launch (ptmi_options.tails) */
 } ptmi_stats;
 
 /* ---- lifetime ----------------------------------------------------------- */

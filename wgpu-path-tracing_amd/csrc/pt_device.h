@@ -45,6 +45,7 @@ struct DevScene {
     // edge is not finite): such rays take the triangle test whose short reciprocal has no range test (pt_math.h)
     float tri_safe_dsum;
     uint32_t q_cached;          // the first q_cached quantised nodes are the top levels in breadth-first order (kept in LDS)
+    uint32_t leaf_bits;         // bits needed for the triangle count of the largest leaf (4 triangles -> 3): the work list's prefix sums
 };
 
 // ---- path state: 56 B per path, four streams indexed by path id ----
@@ -111,12 +112,14 @@ struct TraverseConfig {
     uint32_t *spill;        // global variant: per-lane overflow of the node stack, pt_spill_bytes(blocks) bytes
     int wants_spill;        // the variant needs one (the caller supplies `spill`: each concurrently running kernel its own)
     int quantized;          // global variant: walk the quantised image when the scene has one
+    int worklist;           // LDS variant: triangle tests through the per-wave work list (traverse.hip trace_wave_wl)
 };
 #ifndef PT_QCACHE_NODES
 #define PT_QCACHE_NODES 256      /* quantised nodes of the top levels staged in LDS per workgroup (8 KB) */
 #endif
 #define PT_SPILL_ENTRIES 64     /* >= the deepest node stack: upload rejects trees deeper than 62 */
 size_t pt_spill_bytes(int blocks);
+size_t pt_worklist_bytes(void);  // LDS a 1024-thread workgroup needs for its waves' work lists
 
 // ---- launchers (each enqueues on `s`; grids are persistent, sized by the caller) ----
 void pt_launch_raygen(hipStream_t s, int blocks, const ptmi_camera &cam, DevBand band, uint32_t frame0,

@@ -84,6 +84,9 @@ namespace {
 constexpr int kStatsWords = 8 + 64;
 constexpr int kShadowCount = 72;          // slot of the shadow-queue length in ctx->counts (80 words)
 constexpr size_t kLdsMax = 160 * 1024;
+#ifndef PT_WORKLIST_DEFAULT
+#define PT_WORKLIST_DEFAULT 0          /* what ptmi_options.worklist = 0 means (measured: profiles/README.md) */
+#endif
 
 int fail(const ptmi_ctx *c, int code, const char *fmt, ...) {
     char buf[512];
@@ -206,6 +209,7 @@ struct Built {
     std::vector<uint4> qnodes; std::vector<uint32_t> leaf_stream;     // quantised image (empty: none)
     float q_origin[3] = {0, 0, 0}, q_scale[3] = {0, 0, 0};
     uint32_t q_top = 0;                      // quantised nodes numbered breadth-first at the front (LDS-resident in the kernel)
+    uint32_t max_leaf_tris = 0;
 };
 
 uint32_t leaf_ref(const ptmi_bvh_node &n) {
@@ -249,6 +253,7 @@ int build_image(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_
                 return fail(c, PTMI_E_UNSUPPORTED, "BVH leaf %u starts at triangle %u but an earlier leaf of the left-first DFS ends at %llu: "
                             "leaf ranges must ascend in DFS order (as bvh.ts builds them)", it.node, n.triangle_offset, (unsigned long long)next_offset);
             next_offset = (uint64_t)n.triangle_offset + n.triangle_count;
+            b.max_leaf_tris = std::max(b.max_leaf_tris, n.triangle_count);
             continue;
         }
         wide_of[it.node] = n_wide++;
@@ -354,7 +359,12 @@ TraverseConfig traverse_config(const ptmi_ctx *c, bool closest_hit) {
     // `shade` stretches from 16.5 to 18.3 ms and config 1 loses 4 % (9 767 -> 9 344); with one workgroup it is 40 % slower itself.
     else if ((closest_hit || PT_SHADOW_NODE_CACHE) && node_cache && c->opt.traversal == PTMI_TRAVERSAL_AUTO) {
         cfg.variant = PT_VARIANT_LDS_NODES; cfg.stack_entries = small_stack;
-    } else if (fits) { cfg.variant = PT_VARIANT_LDS; cfg.stack_entries = lds_stack; }
+    } else if (fits) {
+        cfg.variant = PT_VARIANT_LDS; cfg.stack_entries = lds_stack;
+        // the per-wave work list of triangle tests (traverse.hip trace_wave_wl): 16-entry stacks only, and room for the rings
+        const bool wl_on = c->opt.worklist == 2 || (c->opt.worklist == 0 && PT_WORKLIST_DEFAULT);
+        cfg.worklist = wl_on && lds_stack == 16 && c->lds_scene_bytes + (size_t)16 * 1024 * 4 + pt_worklist_bytes() <= kLdsMax;
+    }
     else if (have && closest_hit && c->opt.traversal == PTMI_TRAVERSAL_AUTO &&
              (size_t)c->sc.n_wnodes * 64 + (size_t)16 * 1024 * 4 <= kLdsMax) {
         // mid-size trees (up to 1536 wide nodes): all nodes in LDS, one workgroup per CU, stacks spill. Measured on
@@ -526,6 +536,7 @@ int ptmi_upload_scene(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const
     s.qnodes = c->d_qnodes; s.leaf_stream = c->d_leaf_stream;
     for (int k = 0; k < 3; k++) { s.q_origin[k] = b.q_origin[k]; s.q_scale[k] = b.q_scale[k]; }
     s.q_cached = b.q_top;
+    s.leaf_bits = 0; while ((1u << s.leaf_bits) <= b.max_leaf_tris) s.leaf_bits++;      // counts 0 .. max need that many bits
     s.tri_safe_dsum = b.tri_safe_dsum;
     for (int k = 0; k < 3; k++) { s.root_min[k] = b.root_min[k]; s.root_max[k] = b.root_max[k]; }
     s.root_ref = fast ? b.fast_root : b.root_ref;
@@ -577,6 +588,8 @@ int ptmi_set_options(ptmi_ctx *c, const ptmi_options *o) {
     if (o->perf_mode > 1) return fail(c, PTMI_E_INVALID, "unknown perf_mode %u", o->perf_mode);
     if (o->ray_sort > 2) return fail(c, PTMI_E_INVALID, "unknown ray_sort %u", o->ray_sort);
     if (o->overlap > 3) return fail(c, PTMI_E_INVALID, "unknown overlap %u", o->overlap);
+    if (o->worklist > 2) return fail(c, PTMI_E_INVALID, "unknown worklist %u", o->worklist);
+    if (o->tails > 2) return fail(c, PTMI_E_INVALID, "unknown tails %u", o->tails);
     c->opt = *o;
     return PTMI_OK;
 }
@@ -641,6 +654,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
 #endif
     c->st.traversal_used = cfg0.variant == PT_VARIANT_GLOBAL ? PTMI_TRAVERSAL_GLOBAL : PTMI_TRAVERSAL_LDS;
     c->st.frames_per_batch_used = Fsub;
+    c->st.worklist_used = (cfg0.worklist ? 1u : 0u) | ((nee && cfg_shadow0.worklist) ? 2u : 0u);
     c->st.radiance_stride_bytes = 4u * (PT_L_STRIDE ? (uint32_t)PT_L_STRIDE : ((cfg0.quantized || cfg_shadow0.quantized) ? 4u : 3u));
     const int blocks = c->n_cu * 8;
 #ifndef PT_SHADE_WGS_PER_CU
@@ -875,6 +889,7 @@ int ptmi_debug_intersect(ptmi_ctx *c, uint32_t n, const float *o3, const float *
         return fail(c, PTMI_E_UNSUPPORTED, "scene does not fit in LDS");
     if (cfg.wants_spill && !ln.d_spill) HIP_TRY(c, hipMalloc(&ln.d_spill, pt_spill_bytes(c->n_cu * 8)));
     cfg.spill = ln.d_spill;
+    c->st.worklist_used = cfg.worklist ? 1u : 0u;
     pt_launch_extend(c->stream, c->n_cu * 8, cfg, c->sc, ln.paths, nullptr, &ln.counts[0], ln.hits);
     // (u, v) are not part of the hit record: rebuilt exactly as `shade` rebuilds them (into the C stream, unused here)
     pt_launch_hit_uv(c->stream, n, c->sc, ln.paths, ln.hits, ln.paths.C);
@@ -905,6 +920,7 @@ int ptmi_debug_occluded(ptmi_ctx *c, uint32_t n, const float *o3, const float *d
     TraverseConfig cfg = traverse_config(c, false);
     if (cfg.wants_spill && !ln.d_spill) HIP_TRY(c, hipMalloc(&ln.d_spill, pt_spill_bytes(c->n_cu * 8)));
     cfg.spill = ln.d_spill;
+    c->st.worklist_used = cfg.worklist ? 2u : 0u;
     pt_launch_shadow(c->stream, c->n_cu * 8, cfg, c->sc, ln.paths, ln.sh[0], nullptr, &ln.counts[0], ln.d_occ);
     HIP_TRY(c, hipMemcpyAsync(occ, ln.d_occ, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, sync_all(c));

@@ -497,6 +497,228 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
 #endif
 }
 
+// ---- PER-WAVE WORK LIST (ptmi_options.worklist) --------------------------------------------------------------------------
+// The loop above lets every lane test the 1 - 4 triangles of ITS OWN leaf: a triangle iteration runs with 0.59 of the lanes
+// (Cornell, profiles/r02_cfg1_lane_stats.json). Here a lane that opens a leaf only LISTS its triangles: (its lane number,
+// triangle) items go into a ring of WL_RING words in LDS that belongs to the wave, and whenever the ring holds 64 items all 64
+// lanes take one each — the ray (origin, direction; the any-hit limit) comes from the listing lane's registers through
+// ds_bpermute, the triangle from the scene image as before. Results go back through LDS: the closest hit as ONE 64-bit minimum
+// on (bits(t) << 32 | triangle) per ray — for t > 0 the order of the bit patterns is the order of the floats, so the minimum IS
+// the contract's (smallest t, lowest triangle index) rule of pt.wgsl:274 / DESIGN.md §3.2 — the any-hit verdict as a flag.
+// A ray's distance limit then lags by up to a ring's worth of triangles, which is conservative (a stale limit culls less).
+// A ray is finished when it has no node, no filed leaf and no listed triangle left (my_end <= head); partly filled rounds of 64
+// are only run when too many lanes wait for exactly that (WL_FLUSH_WAIT) or nothing else is left to do. An occluded shadow ray
+// finishes at once; its lane is refilled only after its listed triangles have drained (their owner lane must not change).
+// The box stream is the one above, unchanged.
+#ifndef PT_WL_RING
+#define PT_WL_RING 256
+#endif
+#ifndef PT_WL_FLUSH_WAIT
+#define PT_WL_FLUSH_WAIT 12
+#endif
+constexpr uint32_t WL_RING = PT_WL_RING;                  // items (a power of two, >= 64 + PT_LEAF_MAX_TRIS)
+constexpr uint32_t WL_WORDS = 128u + WL_RING;            // per wave: 64 keys of 8 bytes, then the ring
+static_assert((WL_RING & (WL_RING - 1u)) == 0u && WL_RING >= 64u + PT_LEAF_MAX_TRIS, "ring size");
+typedef __attribute__((address_space(3))) unsigned long long *lds_u64p;
+PT_DEV uint32_t mbcnt(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+PT_DEV float bperm(uint32_t byte_addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute((int)byte_addr, __float_as_int(v))); }
+
+template <int MODE, bool CULL, int STACK, int REFILL, class Mem, class IO>
+PT_DEV void trace_wave_wl(const Mem &m, const DevScene &sc, const IO &io, uint32_t count, uint32_t gw,
+                          uint32_t total_waves, uint32_t *stk, int stride, uint32_t *wl) {
+    constexpr bool ANY = MODE == MODE_SHADOW;
+    constexpr int NODE_KEEP = ANY ? 2 : 3;
+    constexpr unsigned long long KEY_NONE = ANY ? 0ull : ((0x7F800000ull << 32) | 0xFFFFFFFFull);     // (t = +inf, no triangle)
+    const uint32_t lane = threadIdx.x & 63u;
+    gw = uniform(gw);
+    const uint32_t ngroups = (count + 63u) >> 6;
+    const uint32_t end = gw < ngroups ? ((ngroups - gw + total_waves - 1u) / total_waves) * 64u : 0u;
+    uint32_t next = 0u;
+    bool active = false, slow = false, occ = false;
+    const bool has_fast = sc.has_fast != 0u;
+    const uint32_t leaf_bits = uniform(sc.leaf_bits);
+    uint32_t slot = 0, cur = PT_REF_NONE;
+    const lds_u32p bot = (lds_u32p)stk, top = bot + (STACK - 1) * stride;
+    lds_u32p sp = bot, lp = top;
+    const lds_u64p keys = (lds_u64p)wl;
+    const lds_u32p ring = (lds_u32p)wl + 128;
+    uint32_t head = 0u, tail = 0u;          // wave-uniform: items [head, tail) are listed and not yet tested (indices modulo WL_RING)
+    uint32_t my_end = 0u;                   // tail after this lane's last listing: it has items pending while my_end - head > 0
+    v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), inv = mk3(0, 0, 0);
+    float tlim = 0.0f, limit = __builtin_inff();
+    keys[lane] = KEY_NONE;
+#ifdef PT_UTIL_STATS
+    uint32_t ut[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+
+    for (;;) {
+        bool pend = (int)(my_end - head) > 0;
+        uint64_t act = ballot(active);
+        if (next < end && popc(act) <= REFILL) {
+            const bool free_lane = !active & !pend;
+            const uint64_t idle = ballot(free_lane);
+            const uint32_t vi = next + mbcnt(idle);
+            const uint32_t vslot = ((vi >> 6) * total_waves + gw) * 64u + (vi & 63u);
+            if (free_lane && vi < end && vslot < count) {
+                slot = vslot;
+                const bool want = io.fetch(slot, o, d, tlim);
+                inv = mk3(rcp1(d.x), rcp1(d.y), rcp1(d.z));
+                keys[lane] = KEY_NONE; occ = false;
+                sp = bot; lp = top; cur = PT_REF_NONE; my_end = head;
+                limit = (ANY && CULL) ? cull_limit(tlim) : __builtin_inff();
+                const bool regular = __builtin_isfinite(inv.x) & __builtin_isfinite(inv.y) & __builtin_isfinite(inv.z) &
+                                     (inv.x != 0.0f) & (inv.y != 0.0f) & (inv.z != 0.0f);
+                const bool bounded = (__builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z)) <= sc.tri_safe_dsum;
+                slow = !(regular & bounded);
+                float tm;
+                if (want && sc.root_ref != PT_REF_NONE &&
+                    slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2],
+                         o, inv, tm)) {
+                    active = true;
+                    const uint32_t r = (has_fast & slow) ? sc.ref_root_ref : sc.root_ref;
+                    if (r & PT_REF_LEAF) { *lp = r; lp -= stride; }
+                    else cur = r;
+                } else {
+                    Hit none; none.t = __builtin_inff(); none.tri = PT_REF_NONE;
+                    io.finish(slot, none, false);
+                }
+            }
+            next += (uint32_t)popc(idle);
+            UTIL(2, 1); UTIL(3, popc(ballot(active)) - popc(act));
+            act = ballot(active);
+        }
+        if (act == 0ull) {
+            if (next >= end) break;
+            head = tail;                    // what is still listed belongs to finished (occluded) rays: drop it, their lanes are free again
+            continue;
+        }
+        UTIL(0, 1); UTIL(1, popc(act));
+
+        const bool can_node = active & (cur != PT_REF_NONE) & room2(lp, sp, stride);
+        const bool can_tri = active & (lp != top);
+        const uint64_t bn = ballot(can_node), bt = ballot(can_tri);
+        const uint32_t listed = tail - head;
+        const int waiting = popc(ballot(active & pend & !can_node & !can_tri));     // lanes with nothing left but listed triangles
+        int what = -1;                      // 0: box-pair steps, 1: list the triangles of filed leaves, 2: test listed triangles
+        if (listed >= 64u || (listed != 0u && waiting >= PT_WL_FLUSH_WAIT)) what = 2;
+        else if (popc(bt) > popc(bn)) what = 1;
+        else if (bn != 0ull) what = 0;
+        else if (bt != 0ull) what = 1;
+        else if (listed != 0u) what = 2;
+        auto streams = [&](auto with_ref) {
+        constexpr bool REF = decltype(with_ref)::value;
+        if (what == 2) {
+            do {
+                const uint32_t n = tail - head < 64u ? tail - head : 64u;
+                const bool valid = lane < n;
+                UTIL(8, lane == 0u ? 1 : 0); UTIL(9, valid ? 1 : 0);
+                uint32_t item = ring[(head + lane) & (WL_RING - 1u)];
+                item = valid ? item : 0u;                          // lane 0's ray against triangle 0, result unused
+                const uint32_t owner = item >> PT_LEAF_OFF_BITS, ti = item & PT_LEAF_OFF_MASK;
+                const uint32_t oa = owner << 2;
+                const v3 ro = mk3(bperm(oa, o.x), bperm(oa, o.y), bperm(oa, o.z));
+                const v3 rd = mk3(bperm(oa, d.x), bperm(oa, d.y), bperm(oa, d.z));
+                float4 a, b, c;
+                m.tri(ti, 0u, false, a, b, c);
+                float u = 0.0f, v = 0.0f;
+                const float t = tri_test_t<!REF>(xyz(a), xyz(b), xyz(c), ro, rd, u, v);
+                const bool hit = valid & (t > 0.0f);
+                if (ANY) {
+                    const float rl = bperm(oa, tlim);
+                    if (hit & !(t >= rl)) *(lds_u32p)(keys + owner) = 1u;
+                } else if (hit) {
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | ti;
+                    __hip_atomic_fetch_min(keys + owner, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+                head += n;
+            } while (tail - head >= 64u);
+            // every ray picks up what the round found for it
+            if (ANY) occ = *(lds_u32p)(keys + lane) != 0u;
+            else if (CULL) limit = cull_limit(__uint_as_float((uint32_t)(keys[lane] >> 32)));
+        } else if (what == 1) {
+            uint32_t room = WL_RING - listed;
+#pragma unroll 1
+            for (int rep = 0; rep < LEAF_STEPS; rep++) {
+                const bool ct = active & (lp != top);
+                UTIL(6, 1); UTIL(7, popc(ballot(ct)));
+                uint32_t first = 0u, cnt = 0u, cursor;
+                if (ct) open_plain(*(lp + stride), first, cnt, cursor);
+                uint32_t pre = 0u, tot = 0u;                        // exclusive prefix and total of cnt over the wave, bit by bit
+                for (uint32_t b = 0; b < leaf_bits; b++) {
+                    const uint64_t mb = ballot(((cnt >> b) & 1u) != 0u);
+                    pre += mbcnt(mb) << b; tot += (uint32_t)popc(mb) << b;
+                }
+                if (tot == 0u) break;
+                const bool ok = ct & (pre + cnt <= room);          // a prefix of the listing lanes (pre ascends with the lane)
+                const uint64_t bok = ballot(ok);
+                if (bok == 0ull) break;
+                if (ok) {
+                    for (uint32_t k = 0; k < cnt; k++) ring[(tail + pre + k) & (WL_RING - 1u)] = (lane << PT_LEAF_OFF_BITS) | (first + k);
+                    my_end = tail + pre + cnt;
+                    lp += stride;
+                }
+                uint32_t pushed = tot;
+                if (tot > room) pushed = (uint32_t)__builtin_amdgcn_readlane((int)(pre + cnt), 63 - __builtin_clzll(bok));
+                tail += pushed; room -= pushed;
+                if (rep + 1 < LEAF_STEPS && popc(ballot(active & (lp != top))) * LEAF_KEEP < popc(bt)) break;
+            }
+        } else if (what == 0) {
+            bool cn = can_node;
+#pragma unroll
+            for (int rep = 0; rep < NODE_STEPS; rep++) {
+                UTIL(4, 1); UTIL(5, popc(ballot(cn)));
+                if (cn) {
+                    float tl, tr;
+                    bool hl, hr;
+                    uint32_t lref, rref;
+                    Boxes nb;
+                    if (REF && has_fast && slow) {
+                        float4 a, b, c, r;
+                        load_node((glb_f4p)sc.ref_wnodes + 4u * (size_t)cur, a, b, c, r);
+                        boxes_of(a, b, c, r, nb);
+                    } else {
+                        m.node(cur, false, nb);
+                    }
+                    hl = slab(nb.lx0, nb.ly0, nb.lz0, nb.lx1, nb.ly1, nb.lz1, o, inv, tl);
+                    hr = slab(nb.rx0, nb.ry0, nb.rz0, nb.rx1, nb.ry1, nb.rz1, o, inv, tr);
+                    lref = nb.lref; rref = nb.rref;
+                    if (CULL) { hl = hl & !(tl > limit); hr = hr & !(tr > limit); }
+                    const bool ll = (lref & PT_REF_LEAF) != 0u, rl = (rref & PT_REF_LEAF) != 0u;
+                    if (hl & ll) { *lp = lref; lp -= stride; }
+                    if (hr & rl) { *lp = rref; lp -= stride; }
+                    const bool il = hl & !ll, ir = hr & !rl;
+                    const bool left_first = tl <= tr;
+                    if (il & ir) { *sp = left_first ? rref : lref; sp += stride; cur = left_first ? lref : rref; }
+                    else if (il) cur = lref;
+                    else if (ir) cur = rref;
+                    else if (sp != bot) { sp -= stride; cur = *sp; }
+                    else cur = PT_REF_NONE;
+                }
+                if (rep + 1 < NODE_STEPS) {
+                    cn = cn & (cur != PT_REF_NONE) & room2(lp, sp, stride);
+                    if (popc(ballot(cn)) * NODE_KEEP < popc(bn)) break;
+                }
+            }
+        }
+        };
+        if (ballot(slow & active) != 0ull) streams(std::true_type{});
+        else streams(std::false_type{});
+        pend = (int)(my_end - head) > 0;
+        // hang guard: nothing could run for anybody (cannot happen while STACK > tree depth): active lanes end with what they have
+        const bool done = active & (occ | (what < 0) | ((cur == PT_REF_NONE) & (lp == top) & !pend));
+        if (done) {
+            Hit best; best.t = __builtin_inff(); best.tri = PT_REF_NONE;
+            if (!ANY) { const unsigned long long k = keys[lane]; best.t = __uint_as_float((uint32_t)(k >> 32)); best.tri = (uint32_t)k; }
+            io.finish(slot, best, occ);
+            active = false; cur = PT_REF_NONE; lp = top;
+        }
+    }
+#ifdef PT_UTIL_STATS
+    if (lane == 0u) for (int i = 0; i < 8; i++) atomicAdd(&g_util[MODE][i], (unsigned long long)ut[i]);
+    for (int i = 8; i < 10; i++) if (ut[i]) atomicAdd(&g_util[MODE][i], (unsigned long long)ut[i]);
+#endif
+}
+
 // ------------------------------------------------------------------ global ----
 constexpr int GBLOCK = 256;
 
@@ -546,7 +768,7 @@ __global__ __launch_bounds__(GBLOCK) PT_GLOBAL_ATTR void k_trace_global(DevScene
 // triangle and miss the LDS-resident triangles); ptmi_api picks per kernel.
 constexpr int LBLOCK = 1024;
 
-template <int MODE, bool CULL, int STACK, bool TRIS_IN_LDS, bool SPILL, class IO>
+template <int MODE, bool CULL, int STACK, bool TRIS_IN_LDS, bool SPILL, bool WL, class IO>
 __global__ __launch_bounds__(LBLOCK) void k_trace_lds(DevScene sc, IO io, const uint32_t *__restrict__ count_ptr,
                                                       uint32_t *__restrict__ spill) {
     extern __shared__ float4 smem[];
@@ -560,11 +782,17 @@ __global__ __launch_bounds__(LBLOCK) void k_trace_lds(DevScene sc, IO io, const 
     if (gw * 64u >= count) return;
     LdsMem<TRIS_IN_LDS> m{(lds_f4p)smem, (lds_f4p)(smem + nw), (glb_f4p)sc.tripos};
     uint32_t *stk = reinterpret_cast<uint32_t *>(smem + nw + nt) + threadIdx.x;
-    trace_wave<MODE, CULL, STACK, SPILL, REFILL_AT>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk, LBLOCK,
-                                         SPILL ? spill + (size_t)blockIdx.x * LBLOCK + threadIdx.x : nullptr, gridDim.x * LBLOCK);
+    if constexpr (WL) {
+        static_assert(!SPILL, "the work-list loop has no spilling stack");
+        uint32_t *wl = reinterpret_cast<uint32_t *>(smem + nw + nt) + (size_t)STACK * LBLOCK + (threadIdx.x >> 6) * WL_WORDS;
+        trace_wave_wl<MODE, CULL, STACK, REFILL_AT>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk, LBLOCK, wl);
+    } else {
+        trace_wave<MODE, CULL, STACK, SPILL, REFILL_AT>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk, LBLOCK,
+                                             SPILL ? spill + (size_t)blockIdx.x * LBLOCK + threadIdx.x : nullptr, gridDim.x * LBLOCK);
+    }
 }
 
-template <int MODE, bool CULL, int STACK, bool TRIS, bool SPILL = false, class IO>
+template <int MODE, bool CULL, int STACK, bool TRIS, bool SPILL = false, bool WL = false, class IO>
 void launch_lds(hipStream_t s, int wgs, size_t bytes, const DevScene &sc, const IO &io, const uint32_t *count,
                 uint32_t *spill = nullptr) {
     // the default dynamic-LDS cap is 64 KB; raise it once per instantiation and device
@@ -573,11 +801,11 @@ void launch_lds(hipStream_t s, int wgs, size_t bytes, const DevScene &sc, const 
     (void)hipGetDevice(&dev);
     const uint64_t bit = 1ull << (dev & 63);
     if (!(raised.load(std::memory_order_relaxed) & bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_lds<MODE, CULL, STACK, TRIS, SPILL, IO>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_lds<MODE, CULL, STACK, TRIS, SPILL, WL, IO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         raised.fetch_or(bit, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((k_trace_lds<MODE, CULL, STACK, TRIS, SPILL, IO>), dim3(wgs), dim3(LBLOCK), bytes, s, sc, io, count, spill);
+    hipLaunchKernelGGL((k_trace_lds<MODE, CULL, STACK, TRIS, SPILL, WL, IO>), dim3(wgs), dim3(LBLOCK), bytes, s, sc, io, count, spill);
 }
 
 // The persistent grid of the global variant is exactly the workgroups that are resident at once: every workgroup
@@ -623,7 +851,8 @@ void launch(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene
         else launch_lds<MODE, CULL, 16, false>(s, wgs, bytes, sc, io, count);
     } else if (cfg.variant == PT_VARIANT_LDS) {                // everything resident, one workgroup per CU
         const size_t bytes = cfg.lds_scene_bytes + stack_bytes;
-        if (cfg.stack_entries <= 16) launch_lds<MODE, CULL, 16, true>(s, cus, bytes, sc, io, count);
+        if (cfg.worklist && cfg.stack_entries <= 16) launch_lds<MODE, CULL, 16, true, false, true>(s, cus, bytes + pt_worklist_bytes(), sc, io, count);
+        else if (cfg.stack_entries <= 16) launch_lds<MODE, CULL, 16, true>(s, cus, bytes, sc, io, count);
         else launch_lds<MODE, CULL, 32, true>(s, cus, bytes, sc, io, count);
     } else {
         launch_global<MODE, CULL>(s, cus, sc, io, count, cfg.spill, cfg.quantized != 0);
@@ -651,6 +880,8 @@ void pt_launch_shadow(hipStream_t s, int blocks, const TraverseConfig &cfg, cons
     if (cfg.cull) launch<MODE_SHADOW, true>(s, blocks, cfg, sc, io, count);
     else launch<MODE_SHADOW, false>(s, blocks, cfg, sc, io, count);
 }
+
+size_t pt_worklist_bytes(void) { return (size_t)(LBLOCK / 64) * WL_WORDS * sizeof(uint32_t); }
 
 size_t pt_spill_bytes(int blocks) {
     const int cus = blocks / 8 > 0 ? blocks / 8 : 1;

@@ -24,7 +24,7 @@ EXPORTS = [
     "ptmi_debug_raygen", "ptmi_debug_intersect", "ptmi_debug_occluded", "ptmi_debug_math", "ptmi_debug_exact_math", "ptmi_get_size",
     "ptmi_debug_image_stats",
 ]
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class PtmiError(RuntimeError):
@@ -40,7 +40,7 @@ class Options(ctypes.Structure):
                 ("cull", ctypes.c_uint32), ("timing", ctypes.c_uint32), ("keep_reference_tree", ctypes.c_uint32),
                 ("tile_parts", ctypes.c_uint32), ("tile_part", ctypes.c_uint32), ("tile_strip", ctypes.c_uint32),
                 ("perf_mode", ctypes.c_uint32), ("ray_sort", ctypes.c_uint32), ("overlap", ctypes.c_uint32),
-                ("reserved", ctypes.c_uint32 * 1)]
+                ("worklist", ctypes.c_uint32), ("tails", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 6)]
 
 
 class Stats(ctypes.Structure):
@@ -53,7 +53,8 @@ class Stats(ctypes.Structure):
                 ("frames_per_batch_used", ctypes.c_uint32), ("radiance_stride_bytes", ctypes.c_uint32),
                 ("shadow_traced", ctypes.c_uint64), ("shade_launches", ctypes.c_uint64), ("shadow_launches", ctypes.c_uint64),
                 ("raygen_ms", ctypes.c_double), ("compact_ms", ctypes.c_double), ("accumulate_ms", ctypes.c_double),
-                ("upload_ms", ctypes.c_double), ("upload_tree_ms", ctypes.c_double), ("upload_copy_ms", ctypes.c_double)]
+                ("upload_ms", ctypes.c_double), ("upload_tree_ms", ctypes.c_double), ("upload_copy_ms", ctypes.c_double),
+                ("worklist_used", ctypes.c_uint32), ("tails_used", ctypes.c_uint32)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("segments_by_bounce", "reserved")}
