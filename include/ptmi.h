@@ -175,6 +175,59 @@ int ptmi_blit(ptmi_ctx *ctx, float *dst_rgba_f32, size_t n_floats, uint8_t *dst_
 /* Size of the output buffer as last set by ptmi_resize (0 x 0 before). */
 int ptmi_get_size(const ptmi_ctx *ctx, uint32_t *width, uint32_t *height);
 
+/* ---- several GPUs of one node behind the same boundary (BASELINE configs[4]) ----------------------------------
+ * The caller this serves is the frame loop of src/renderer/renderer.ts:415-454: one host thread, one `Renderer`, now over N
+ * devices. Pixels are independent (pt.wgsl:753-761) and the RNG is seeded per (x, y, frame) (random.wgsl:3-5), so the frame's
+ * rows are dealt to the devices as interleaved strips (tile_parts / tile_part / tile_strip above) with no data-path collective:
+ * every device holds the whole scene, traces all frames of ITS rows and accumulates them locally. ptmi_multi_gather packs each
+ * device's rows into one contiguous buffer, moves them to device 0 with ONE RCCL gather over xGMI (ncclGather,
+ * /opt/rocm/include/rccl/rccl.h:745; single process, ncclCommInitAll over the listed devices) and unpacks them by row index into
+ * device 0's output buffer, which then holds the frame exactly as one device would have rendered it — bit for bit.
+ * librccl.so.1 is loaded when the first multi-device handle is created (not by single-device users of this library).
+ * All calls are made from one host thread; work is enqueued asynchronously on one stream per device. */
+typedef struct ptmi_multi ptmi_multi;
+enum {
+    PTMI_MULTI_LOOPBACK = 1u    /* device-to-device copies in place of the collective: lets ONE device stand in for several (the same
+                                   ordinal may then be listed more than once) — for tests of the packing on a one-GPU box; RCCL is not loaded */
+};
+/* ordinals: n_devices HIP device ordinals (NULL = 0 .. n_devices-1); the first one is the root that ends up with the frame. */
+int ptmi_multi_create(int n_devices, const int *ordinals, uint32_t flags, ptmi_multi **out);
+int ptmi_multi_destroy(ptmi_multi *m);
+const char *ptmi_multi_last_error(const ptmi_multi *m);       /* m may be NULL for creation errors */
+int ptmi_multi_count(const ptmi_multi *m);
+ptmi_ctx *ptmi_multi_context(ptmi_multi *m, int i);           /* device i's context (statistics, per-stage entry points); owned by m */
+/* ptmi_upload_scene / _atlas / ptmi_resize on every device (the scene is replicated: <= 163 MB in BASELINE's configs) */
+int ptmi_multi_upload_scene(ptmi_multi *m,
+                            const ptmi_triangle *triangles, uint32_t n_triangles,
+                            const ptmi_material *materials, uint32_t n_materials,
+                            const ptmi_bvh_node *bvh_nodes, uint32_t n_nodes,
+                            const ptmi_light *lights, uint32_t n_lights);
+int ptmi_multi_upload_atlas(ptmi_multi *m, const void *texels, uint32_t width, uint32_t height, int format);
+int ptmi_multi_resize(ptmi_multi *m, uint32_t width, uint32_t height);
+/* Options for every device. tile_parts / tile_part are set by the library (device i renders the strips i, i + N, ...);
+ * tile_strip = 0 picks the strip height: 4 rows, or the largest smaller height that makes the frame a whole number of rounds
+ * (3840x2160 over 8 devices: 3), so that all devices get equal shares; tile_y0 / tile_y1 must be 0. */
+int ptmi_multi_set_options(ptmi_multi *m, const ptmi_options *opt);
+int ptmi_multi_get_options(const ptmi_multi *m, ptmi_options *opt);
+/* ptmi_dispatch on every device, each for its own strips. Asynchronous. */
+int ptmi_multi_dispatch(ptmi_multi *m, const ptmi_camera *camera, uint32_t n_frames);
+/* Assembles the frame in device 0's output buffer (pack -> ncclGather -> unpack), ordered after the dispatches so far on every
+ * device's stream. Asynchronous. Call it after the last frame, or every k frames for a preview (the rows keep accumulating on
+ * their devices; the gather only copies). With one device it is a no-op. */
+int ptmi_multi_gather(ptmi_multi *m);
+int ptmi_multi_synchronize(ptmi_multi *m);
+/* gather + synchronise + copy device 0's output buffer out (width*height float4) */
+int ptmi_multi_read_output(ptmi_multi *m, float *dst_rgba, size_t n_floats);
+/* resume: the frame is written to every device (each keeps accumulating its rows on top of it) */
+int ptmi_multi_write_output(ptmi_multi *m, const float *src_rgba, size_t n_floats);
+/* gather + the blit pass on device 0 (see ptmi_blit) */
+int ptmi_multi_blit(ptmi_multi *m, float *dst_rgba_f32, size_t n_floats, uint8_t *dst_rgba8, size_t n_bytes);
+/* counters summed over the devices; times (gpu_ms, *_ms) are the maximum over the devices; the rest is device 0's */
+int ptmi_multi_get_stats(ptmi_multi *m, ptmi_stats *out);
+int ptmi_multi_reset_stats(ptmi_multi *m);
+/* time of the last ptmi_multi_gather on device 0's stream, pack + collective + unpack, in ms (-1 before the first; synchronises) */
+int ptmi_multi_gather_ms(ptmi_multi *m, double *ms);
+
 /* ---- statistics ----------------------------------------------------------- */
 int ptmi_get_stats(ptmi_ctx *ctx, ptmi_stats *out);           /* synchronises */
 int ptmi_reset_stats(ptmi_ctx *ctx);

@@ -18,7 +18,7 @@ sc = scenes.make(name)
 ctx = native.Context(0)
 ctx.upload_scene(sc)
 ctx.resize(W, H)
-ctx.set_options(max_bounces=8, do_mis=1)
+ctx.set_options(max_bounces=8, do_mis=1, **json.loads(os.environ.get("PTMI_OPTS", "{}")))      # e.g. PTMI_OPTS='{"worklist": 2, "traversal": 2}'
 lib = ctypes.CDLL(os.environ["PTMI_LIB"])
 out = (ctypes.c_ulonglong * 32)()
 ctx.dispatch(layout.make_camera(W, H), frames)

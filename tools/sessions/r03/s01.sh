@@ -10,4 +10,3 @@ for i in 1 2 3; do
   run lds_off_$i --config 1 --traversal lds --worklist 1 && run lds_wl_$i --config 1 --traversal lds --worklist 2 && run auto_$i --config 1 || exit 1
 done
 run lds_off_one --config 1 --traversal lds --worklist 1 --overlap 0 && run lds_wl_one --config 1 --traversal lds --worklist 2 --overlap 0 && run auto_one --config 1 --overlap 0 || exit 1
-run c2_off --config 2 --traversal lds --worklist 1; run c2_wl --config 2 --traversal lds --worklist 2

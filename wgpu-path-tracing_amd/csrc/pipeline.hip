@@ -299,6 +299,19 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(DevBand band, uint32_t fra
     }
 }
 
+// ---- multi-GPU gather (ptmi_multi_gather): a device's rows (DevBand: the strips part, part + parts, ...) <-> one contiguous
+// buffer of band.rows x width float4, local row l of the buffer = frame row band.row_of(l)
+__global__ __launch_bounds__(BLOCK) void k_pack_rows(DevBand band, const float4 *__restrict__ frame, float4 *__restrict__ packed) {
+    const uint32_t n = band.rows * band.width;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+        packed[i] = frame[(size_t)band.row_of(i / band.width) * band.width + i % band.width];
+}
+__global__ __launch_bounds__(BLOCK) void k_unpack_rows(DevBand band, const float4 *__restrict__ packed, float4 *__restrict__ frame) {
+    const uint32_t n = band.rows * band.width;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+        frame[(size_t)band.row_of(i / band.width) * band.width + i % band.width] = packed[i];
+}
+
 // ---- presentation: src/shader/blit.wgsl:43-155 (exposure 2^1, AgX, look, EOTF, gamma 1/2.2) -------------
 // Not on the parity-exact path: log2 / pow are the device's own (accurate) library functions; the
 // test bar is |gpu - oracle| <= 2e-5 per channel and equal 8-bit codes on >= 99.9 % of pixels.
@@ -431,6 +444,12 @@ void pt_launch_compact(hipStream_t s, int tiles, const uint32_t *queue, const ui
 void pt_launch_accumulate(hipStream_t s, int blocks, DevBand band, uint32_t frame0, uint32_t n_frames,
                           const float *L, uint32_t l_stride, float4 *out) {
     hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(BLOCK), 0, s, band, frame0, n_frames, L, l_stride, out);
+}
+void pt_launch_pack_rows(hipStream_t s, int blocks, DevBand band, const float4 *frame, float4 *packed) {
+    hipLaunchKernelGGL(k_pack_rows, dim3(blocks), dim3(BLOCK), 0, s, band, frame, packed);
+}
+void pt_launch_unpack_rows(hipStream_t s, int blocks, DevBand band, const float4 *packed, float4 *frame) {
+    hipLaunchKernelGGL(k_unpack_rows, dim3(blocks), dim3(BLOCK), 0, s, band, packed, frame);
 }
 void pt_launch_blit(hipStream_t s, int blocks, uint32_t W, uint32_t H, const float4 *color, float4 *out_f32,
                     uint32_t *out_rgba8) {

@@ -151,6 +151,18 @@ void pt_launch_accumulate(hipStream_t s, int blocks, DevBand band, uint32_t fram
                           const float *L, uint32_t l_stride, float4 *out);
 void pt_launch_blit(hipStream_t s, int blocks, uint32_t W, uint32_t H, const float4 *color, float4 *out_f32,
                     uint32_t *out_rgba8);
+// a device's rows of the frame <-> a contiguous buffer (ptmi_multi_gather)
+void pt_launch_pack_rows(hipStream_t s, int blocks, DevBand band, const float4 *frame, float4 *packed);
+void pt_launch_unpack_rows(hipStream_t s, int blocks, DevBand band, const float4 *packed, float4 *frame);
+// the rows DevBand describes for a context with these options on a width x height frame (rows = 0: none)
+struct ptmi_options;
+DevBand pt_band_of(const ptmi_options &opt, uint32_t width, uint32_t height);
+// what ptmi_multi.hip needs from a context (ptmi_api.hip)
+struct ptmi_ctx;
+hipStream_t pt_ctx_stream(ptmi_ctx *c);
+float4 *pt_ctx_output(ptmi_ctx *c);
+int pt_ctx_device(const ptmi_ctx *c);
+int pt_ctx_cus(const ptmi_ctx *c);
 void pt_launch_exact_math(hipStream_t s, int which, unsigned long long *out);
 void pt_launch_math(hipStream_t s, int op, uint32_t n, const float *a, const float *b, const float *c, float *out);
 

@@ -55,6 +55,7 @@ struct ptmi_ctx {
     uint64_t batch_seq = 0;                            // batches launched so far (two lanes: batch k runs on lane k & 1)
     bool last_two_lanes = false;                       // how the previous dispatch used the lanes
     mutable std::string err;
+    bool alloc_oom = false;                            // the last failed batch allocation ran out of device memory
     ptmi_options opt{};
 
     // scene (bindings 1, 2, 4, 5, 6)
@@ -173,6 +174,9 @@ hipError_t sync_all(ptmi_ctx *c) {
     return e;
 }
 
+// bytes of device memory a path of a batch takes in ensure_capacity (state 56 + hit 8 + 2 x (record 44 + index 4) + 2 queues + masks)
+constexpr size_t kBytesPerPath = 16 + 16 + 8 + 16 + 8 + 2 * (16 + 16 + sizeof(rgb_sc) + 4) + 2 * 4 + 1 + 1;
+
 int ensure_capacity(ptmi_ctx *c, Lane &ln, size_t n) {
     if (n <= ln.cap) return PTMI_OK;
     HIP_TRY(c, sync_all(c));
@@ -180,19 +184,26 @@ int ensure_capacity(ptmi_ctx *c, Lane &ln, size_t n) {
     size_t cap = (n + 1023) & ~(size_t)1023;
     size_t words = cap / 64 + 1;
     size_t tiles = cap / pt_compact_tile_slots() + 2;
-    HIP_TRY(c, hipMalloc(&ln.paths.O, cap * 16)); HIP_TRY(c, hipMalloc(&ln.paths.D, cap * 16));
-    HIP_TRY(c, hipMalloc(&ln.paths.C, cap * 8)); HIP_TRY(c, hipMalloc(&ln.paths.L, cap * 16));      // room for either stride
-    HIP_TRY(c, hipMalloc(&ln.hits, cap * 8));
+    c->alloc_oom = false;
+    // a failed allocation leaves the lane empty (not half-built) and the runtime's sticky error cleared; ptmi_dispatch retries
+    // with a smaller batch when it chose the size itself
+#define ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc(&(ptr), (bytes)); if (e_ != hipSuccess) { \
+        c->alloc_oom = e_ == hipErrorOutOfMemory; free_batch(ln); (void)hipGetLastError(); \
+        return fail(c, PTMI_E_HIP, "hipMalloc of %zu bytes for a batch of %zu paths failed: %s", (size_t)(bytes), cap, hipGetErrorString(e_)); } } while (0)
+    ALLOC(ln.paths.O, cap * 16); ALLOC(ln.paths.D, cap * 16);
+    ALLOC(ln.paths.C, cap * 8); ALLOC(ln.paths.L, cap * 16);      // room for either stride
+    ALLOC(ln.hits, cap * 8);
     for (int k = 0; k < 2; k++) {
-        HIP_TRY(c, hipMalloc(&ln.sh[k].SO, cap * (16 + 16 + sizeof(rgb_sc))));
+        ALLOC(ln.sh[k].SO, cap * (16 + 16 + sizeof(rgb_sc)));
         ln.sh[k].SD = ln.sh[k].SO + cap; ln.sh[k].SC = reinterpret_cast<rgb_sc *>(ln.sh[k].SO + 2 * cap); ln.sh[k].cap = (uint32_t)cap;
-        HIP_TRY(c, hipMalloc(&ln.sq[k], cap * 4));
+        ALLOC(ln.sq[k], cap * 4);
     }
-    HIP_TRY(c, hipMalloc(&ln.queue[0], cap * 4)); HIP_TRY(c, hipMalloc(&ln.queue[1], cap * 4));
-    HIP_TRY(c, hipMalloc(&ln.alive, words * 8)); HIP_TRY(c, hipMalloc(&ln.shadowm, words * 8));
-    HIP_TRY(c, hipMalloc(&ln.octm, 3 * words * 8)); ln.mask_words = words;
-    HIP_TRY(c, hipMalloc(&ln.word_off, 2 * tiles * 4));
-    HIP_TRY(c, hipMalloc(&ln.d_occ, cap));
+    ALLOC(ln.queue[0], cap * 4); ALLOC(ln.queue[1], cap * 4);
+    ALLOC(ln.alive, words * 8); ALLOC(ln.shadowm, words * 8);
+    ALLOC(ln.octm, 3 * words * 8); ln.mask_words = words;
+    ALLOC(ln.word_off, 2 * tiles * 4);
+    ALLOC(ln.d_occ, cap);
+#undef ALLOC
     ln.cap = cap;
     return PTMI_OK;
 }
@@ -396,6 +407,23 @@ int upload_rays(ptmi_ctx *c, uint32_t n, const float *o3, const float *d3, const
 }
 
 }  // namespace
+
+// rows of a context: all of [y0, y1), or its strips part, part + parts, ... (the last strip may be short)
+DevBand pt_band_of(const ptmi_options &opt, uint32_t W, uint32_t H) {
+    DevBand band{W, H, opt.tile_y0, opt.tile_y1 ? std::min(opt.tile_y1, H) : H,
+                 std::max(1u, opt.tile_strip), std::max(1u, opt.tile_parts), opt.tile_part, 0u};
+    if (band.y0 >= band.y1) return band;
+    const uint32_t range = band.y1 - band.y0;
+    if (band.parts <= 1u) band.rows = range;
+    else
+        for (uint32_t s0 = band.part * band.strip; s0 < range; s0 += band.parts * band.strip)
+            band.rows += std::min(band.strip, range - s0);
+    return band;
+}
+hipStream_t pt_ctx_stream(ptmi_ctx *c) { return c->stream; }
+float4 *pt_ctx_output(ptmi_ctx *c) { return c->d_out; }
+int pt_ctx_device(const ptmi_ctx *c) { return c->device; }
+int pt_ctx_cus(const ptmi_ctx *c) { return c->n_cu; }
 
 extern "C" {
 
@@ -606,22 +634,27 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
         return fail(c, PTMI_E_INVALID, "camera says %ux%u but the output buffer is %ux%u", cam->width, cam->height, c->W, c->H);
     if (n_frames == 0) return PTMI_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    DevBand band{c->W, c->H, c->opt.tile_y0, c->opt.tile_y1 ? std::min(c->opt.tile_y1, c->H) : c->H,
-                 std::max(1u, c->opt.tile_strip), std::max(1u, c->opt.tile_parts), c->opt.tile_part, 0u};
+    const DevBand band = pt_band_of(c->opt, c->W, c->H);
     if (band.y0 >= band.y1) return fail(c, PTMI_E_INVALID, "tile rows [%u,%u) outside the %u-row frame", band.y0, band.y1, c->H);
-    {   // rows of this context: all of [y0, y1), or its strips part, part + parts, ... (the last strip may be short)
-        const uint32_t range = band.y1 - band.y0;
-        if (band.parts <= 1u) band.rows = range;
-        else
-            for (uint32_t s0 = band.part * band.strip; s0 < range; s0 += band.parts * band.strip)
-                band.rows += std::min(band.strip, range - s0);
-        if (band.rows == 0) return PTMI_OK;                     // more parts than strips: nothing to render here
-    }
+    if (band.rows == 0) return PTMI_OK;                         // more parts than strips: nothing to render here
     const uint64_t npix = (uint64_t)band.rows * band.width;
     uint32_t F = c->opt.frames_per_batch;
     // ~128 Mi paths, ~23 GB of state: the last bounces' small queues cost a fixed ~3 ms per batch, so fewer, larger batches
     // (measured at 1080p, Msamples/s: 32 frames 8 920, 64 frames 9 150 - 9 275, 128 frames 9 270 - 9 310)
-    if (F == 0) { F = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, (128ull << 20) / npix)); }
+    const bool auto_F = F == 0;
+    if (auto_F) {
+        F = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, (128ull << 20) / npix));
+        // ... but never more than the device has room for: several contexts may share one device (ranks rehearsed on one GPU, a
+        // Node host beside another process), and eight ranks of one node each size their batch by what THEIR device has free.
+        // Room = free memory + what this context's lanes already hold, less a tenth for the rest (spill areas, blit staging).
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const uint64_t held = (uint64_t)(c->lanes[0].cap + c->lanes[1].cap) * kBytesPerPath;
+            const uint64_t room = (uint64_t)((double)(free_b + held) * 0.9);
+            const uint64_t fit = room / (npix * kBytesPerPath);
+            F = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(F, fit));
+        }
+    }
     F = std::min(F, n_frames);
     const bool nee = c->opt.do_mis && c->sc.n_lights > 0;
     // overlap 1: `shadow` of bounce b on a side stream, beside extend / shade of bounce b + 1. It is then the only kernel that
@@ -635,17 +668,26 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     // 10 - 12 % SLOWER on every config (profiles/README.md): two persistent traversal grids, each sized to own every CU's LDS,
     // take turns instead of sharing.
     const bool side = nee && c->opt.overlap != 0;
-    const bool two_lanes = c->opt.overlap == 3 && F >= 2;
-    const uint32_t Fsub = two_lanes ? (F + 1) / 2 : F;              // frames per traced batch
+    bool two_lanes = c->opt.overlap == 3 && F >= 2;
+    uint32_t Fsub = two_lanes ? (F + 1) / 2 : F;                    // frames per traced batch
     if (npix * Fsub > 0xFFFFFF00ull) return fail(c, PTMI_E_UNSUPPORTED, "batch of %llu paths exceeds 2^32", (unsigned long long)(npix * Fsub));
     const TraverseConfig cfg0 = traverse_config(c, true), cfg_shadow0 = traverse_config(c, false);
     if (c->opt.traversal == PTMI_TRAVERSAL_LDS && cfg0.variant != PT_VARIANT_LDS)
         return fail(c, PTMI_E_UNSUPPORTED, "scene needs %zu B of LDS plus the stack; it does not fit in %zu B", c->lds_scene_bytes, kLdsMax);
     if (two_lanes != c->last_two_lanes) { HIP_TRY(c, sync_all(c)); c->last_two_lanes = two_lanes; }     // lane 0 changes streams
+    for (;;) {
+        rc = PTMI_OK;
+        for (int k = 0; k < (two_lanes ? 2 : 1) && rc == PTMI_OK; k++) rc = ensure_capacity(c, c->lanes[k], (size_t)(npix * Fsub));
+        if (rc == PTMI_OK) break;
+        // out of device memory with a batch size the library chose: halve it and try again (hipMemGetInfo is a snapshot; another
+        // context may have allocated since). A size the caller asked for fails loudly.
+        if (!auto_F || !c->alloc_oom || F <= 1) return rc;
+        F = (F + 1) / 2;
+        two_lanes = c->opt.overlap == 3 && F >= 2;
+        Fsub = two_lanes ? (F + 1) / 2 : F;
+    }
     for (int k = 0; k < (two_lanes ? 2 : 1); k++) {
         Lane &ln = c->lanes[k];
-        rc = ensure_capacity(c, ln, (size_t)(npix * Fsub));
-        if (rc) return rc;
         if (cfg0.wants_spill && !ln.d_spill) HIP_TRY(c, hipMalloc(&ln.d_spill, pt_spill_bytes(c->n_cu * 8)));          // 128 MiB on 256 CUs
         if (cfg_shadow0.wants_spill && !ln.d_spill_side) HIP_TRY(c, hipMalloc(&ln.d_spill_side, pt_spill_bytes(c->n_cu * 8)));
     }

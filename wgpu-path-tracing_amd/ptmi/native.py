@@ -23,7 +23,12 @@ EXPORTS = [
     "ptmi_bind_output_device", "ptmi_set_stream", "ptmi_blit", "ptmi_get_stats", "ptmi_reset_stats",
     "ptmi_debug_raygen", "ptmi_debug_intersect", "ptmi_debug_occluded", "ptmi_debug_math", "ptmi_debug_exact_math", "ptmi_get_size",
     "ptmi_debug_image_stats",
+    "ptmi_multi_create", "ptmi_multi_destroy", "ptmi_multi_last_error", "ptmi_multi_count", "ptmi_multi_context",
+    "ptmi_multi_upload_scene", "ptmi_multi_upload_atlas", "ptmi_multi_resize", "ptmi_multi_set_options", "ptmi_multi_get_options",
+    "ptmi_multi_dispatch", "ptmi_multi_gather", "ptmi_multi_synchronize", "ptmi_multi_read_output", "ptmi_multi_write_output",
+    "ptmi_multi_blit", "ptmi_multi_get_stats", "ptmi_multi_reset_stats", "ptmi_multi_gather_ms",
 ]
+MULTI_LOOPBACK = 1
 ABI_VERSION = 3
 
 
@@ -104,6 +109,25 @@ def load():
         L.ptmi_debug_occluded.argtypes = [vp, u32, vp, vp, vp, vp]
         L.ptmi_debug_math.argtypes = [vp, ctypes.c_int, u32, vp, vp, vp, vp]
         L.ptmi_debug_exact_math.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
+        L.ptmi_multi_last_error.restype = ctypes.c_char_p
+        L.ptmi_multi_last_error.argtypes = [vp]
+        L.ptmi_multi_context.restype = vp
+        L.ptmi_multi_context.argtypes = [vp, ctypes.c_int]
+        L.ptmi_multi_create.argtypes = [ctypes.c_int, vp, u32, vp]
+        L.ptmi_multi_count.argtypes = [vp]
+        for name in ("destroy", "gather", "synchronize", "reset_stats"):
+            getattr(L, "ptmi_multi_" + name).argtypes = [vp]
+        L.ptmi_multi_upload_scene.argtypes = [vp, vp, u32, vp, u32, vp, u32, vp, u32]
+        L.ptmi_multi_upload_atlas.argtypes = [vp, vp, u32, u32, ctypes.c_int]
+        L.ptmi_multi_resize.argtypes = [vp, u32, u32]
+        L.ptmi_multi_set_options.argtypes = [vp, vp]
+        L.ptmi_multi_get_options.argtypes = [vp, vp]
+        L.ptmi_multi_dispatch.argtypes = [vp, vp, u32]
+        L.ptmi_multi_read_output.argtypes = [vp, vp, sz]
+        L.ptmi_multi_write_output.argtypes = [vp, vp, sz]
+        L.ptmi_multi_blit.argtypes = [vp, vp, sz, vp, sz]
+        L.ptmi_multi_get_stats.argtypes = [vp, vp]
+        L.ptmi_multi_gather_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
         _lib = L
     return _lib
 
@@ -264,3 +288,105 @@ class Context:
         n, first = ctypes.c_uint64(0), ctypes.c_uint32(0)
         self._ck(self.L.ptmi_debug_exact_math(self.h, which, ctypes.byref(n), ctypes.byref(first)))
         return int(n.value), int(first.value)
+
+
+class MultiContext:
+    """Several devices of one node behind one handle (include/ptmi.h ptmi_multi_*): the frame's rows are dealt out as
+    interleaved strips, every device accumulates its own, gather() assembles the frame on the first device through RCCL.
+    loopback=True replaces the collective with device-to-device copies, so that one device can stand in for several."""
+
+    def __init__(self, devices, loopback=False):
+        self.L = load()
+        devs = (ctypes.c_int * len(devices))(*devices)
+        h = ctypes.c_void_p()
+        rc = self.L.ptmi_multi_create(len(devices), devs, MULTI_LOOPBACK if loopback else 0, ctypes.byref(h))
+        if rc != 0:
+            raise PtmiError(rc, self.L.ptmi_multi_last_error(None).decode())
+        self.h = h
+        self.n = len(devices)
+        self.width = self.height = 0
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise PtmiError(rc, self.L.ptmi_multi_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ptmi_multi_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def upload_scene(self, scene):
+        self._ck(self.L.ptmi_multi_upload_scene(self.h, _p(scene.tris), len(scene.tris), _p(scene.mats), len(scene.mats),
+                                                _p(scene.nodes), len(scene.nodes), _p(scene.lights), len(scene.lights)))
+        a = scene.atlas
+        if a is None:
+            self._ck(self.L.ptmi_multi_upload_atlas(self.h, None, 0, 0, 0))
+        else:
+            fmt = ATLAS_RGBA16F if a.dtype == np.float16 else ATLAS_RGBA32F
+            self._ck(self.L.ptmi_multi_upload_atlas(self.h, _p(a), a.shape[1], a.shape[0], fmt))
+
+    def resize(self, width, height):
+        self._ck(self.L.ptmi_multi_resize(self.h, width, height))
+        self.width, self.height = width, height
+
+    def set_options(self, **kw):
+        o = Options()
+        self._ck(self.L.ptmi_multi_get_options(self.h, ctypes.byref(o)))
+        o.tile_parts = o.tile_part = 0
+        if "tile_strip" not in kw:
+            o.tile_strip = 0
+        for k, v in kw.items():
+            if not hasattr(o, k):
+                raise TypeError(f"unknown option {k}")
+            setattr(o, k, int(v))
+        self._ck(self.L.ptmi_multi_set_options(self.h, ctypes.byref(o)))
+
+    def options(self):
+        o = Options()
+        self._ck(self.L.ptmi_multi_get_options(self.h, ctypes.byref(o)))
+        return o
+
+    def dispatch(self, camera, n_frames=1):
+        assert camera.dtype == layout.CAMERA
+        self._ck(self.L.ptmi_multi_dispatch(self.h, _p(camera), n_frames))
+
+    def gather(self):
+        self._ck(self.L.ptmi_multi_gather(self.h))
+
+    def synchronize(self):
+        self._ck(self.L.ptmi_multi_synchronize(self.h))
+
+    def read_output(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._ck(self.L.ptmi_multi_read_output(self.h, _p(out), out.size))
+        return out
+
+    def write_output(self, arr):
+        arr = np.ascontiguousarray(arr, np.float32)
+        self._ck(self.L.ptmi_multi_write_output(self.h, _p(arr), arr.size))
+
+    def blit(self):
+        b = np.empty((self.height, self.width, 4), np.uint8)
+        self._ck(self.L.ptmi_multi_blit(self.h, None, 0, _p(b), b.size))
+        return b
+
+    def stats(self):
+        s = Stats()
+        self._ck(self.L.ptmi_multi_get_stats(self.h, ctypes.byref(s)))
+        return s
+
+    def reset_stats(self):
+        self._ck(self.L.ptmi_multi_reset_stats(self.h))
+
+    def gather_ms(self):
+        ms = ctypes.c_double(-1.0)
+        self._ck(self.L.ptmi_multi_gather_ms(self.h, ctypes.byref(ms)))
+        return ms.value
