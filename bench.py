@@ -24,13 +24,16 @@ ONE RCCL gather, inside the timed region. value = all ranks' path segments / max
                across 8x MI355X with RCCL gather").
 Rank r renders the strips r, r + N, ... (4 rows each, fewer when the frame height is not a whole number of such rounds: 3 for 2160 rows over 8 ranks).
 
-Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel against HBM — the kernel with the most device time on
-the stream that carries the bounce loop: on the Cornell scenes `shade` (115 B per segment: queue 4 + hit 8 + ray state 40
-read, 40 written, 44 per emitted record), on the 1 M-triangle scene the closest-hit traversal `extend` (44 B per ray: origin +
-direction 32 + queue index 4 read, hit record 8 written) — with launch durations from HIP events recorded
-by the library around every launch on the stream it runs on (`--timing 3`: every kernel); `roofline.kernels` carries the
-same figures for all three of extend, shade and shadow. `roofline.traffic` replays the committed rocprofv3 counter passes of the same command
-(profiles/<tag>_cfgN_pmc.json, with the commit that made them) — counters cannot be read from inside an un-profiled run.
+Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel against HBM — the kernel with the most device time among
+extend, shade and shadow, whatever stream it runs on (on the Cornell scenes the any-hit traversal `shadow`: 72 B per traced
+record — index 4 + record 44 read, radiance read-modify-write 24; on the 1 M-triangle scene the closest-hit traversal `extend`,
+44 B per ray) — with launch durations from HIP events recorded by the library around every launch on the stream
+it runs on (`--timing 3`: every kernel); `roofline.kernels` carries the same figures for all three kernels, `pipeline_frac` the
+whole dispatch, `valu_issue` the second roofline (vector-ALU issue) with the lane utilisation of each kernel.
+`roofline.traffic` and `roofline.valu_issue` replay the committed rocprofv3 counter passes of the same command
+(profiles/<tag>_cfgN_pmc.json / _counters.json — counters cannot be read from inside an un-profiled run); profiles/<tag>_manifest.json
+names the commit and the hash of the kernel sources they were measured on, and both carry `stale: true` when the sources of
+this build differ.
 `cpu_baseline` times the CPU oracle (oracle/, a restatement — the reference has no CPU path) on a bounded sample of
 the same workload.
 """
@@ -89,13 +92,27 @@ def pipeline_bytes_per_segment(do_mis, mean_len, l_bytes=12):
     return seg + ((32 + l_bytes) + (l_bytes + 32) - 12 - 8) / max(mean_len, 1e-9)
 
 
-def _git_commit_of(path):
+def csrc_sha():
+    """sha256 over the kernel sources (wgpu-path-tracing_amd/csrc/*.hip, *.h, include/*.h, file names included): what a
+    committed counter file must have been measured on for its replay to describe THIS build."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in (os.path.join(ROOT, "wgpu-path-tracing_amd", "csrc"), os.path.join(ROOT, "include")):
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".hip", ".h")):
+                h.update(f.encode())
+                h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def manifest():
+    """profiles/<tag>_manifest.json (tools/make_manifest.py): commit and source hash of the build the counter files of this tag
+    were measured on, and the sha256 of every file — the GPU box has no git history to ask."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_manifest.json")
     try:
-        out = subprocess.run(["git", "log", "-n", "1", "--format=%h", "--", path], cwd=ROOT, capture_output=True,
-                             text=True, timeout=10).stdout.strip()
-        return out or None
+        return json.load(open(path))
     except Exception:
-        return None
+        return {}
 
 
 def profile_path(config, kind):
@@ -120,7 +137,11 @@ def pmc_traffic(config, is_profiled_workload):
         n = sum(d.get("FETCH_SIZE", {}).get(k, {}).get("launches", 0) for k in keys)
         if n:
             out[label] = int((2 * f + w) / n * 1024)
-    src = {"file": os.path.relpath(path, ROOT), "file_commit": _git_commit_of(path), "code_commit": d.get("_code_commit"),
+    man = manifest()
+    src = {"file": os.path.relpath(path, ROOT), "file_commit": man.get("commit"), "code_commit": d.get("_code_commit"),
+           "manifest": f"profiles/{PROFILE_TAG}_manifest.json" if man else None,
+           # replayed, not measured in this run: stale = the kernel sources have changed since the counters were taken
+           "stale": man.get("csrc_sha") != csrc_sha(),
            "formula": "2*FETCH_SIZE + WRITE_SIZE, bytes per launch (mean over the launches of the profiled run: this config's "
                       "dispatch, one warm-up and one timed step)"}
     return out, src
@@ -147,11 +168,20 @@ def valu_issue(config, is_profiled_workload, launches, gpu_ms):
             per[label] = q
     if len(per) < 3:
         return None
+    # lane utilisation of VALU instructions from the same pass: thread-cycles / (64 x instruction quad-cycles)
+    tc = json.load(open(path)).get("SQ_THREAD_CYCLES_VALU", {})
+    lane_util = {}
+    for label, keys in (("extend", ("k_trace_lds/extend", "k_trace_global/extend")),
+                        ("shadow", ("k_trace_lds/shadow", "k_trace_global/shadow")), ("shade", ("k_shade",))):
+        t = sum(tc.get(k, {}).get("avg_per_launch", 0.0) for k in keys)
+        if t and per.get(label):
+            lane_util[label] = round(t / (64.0 * per[label]), 4)
     busy_ms = {k: 4.0 * q * launches.get(k, 0) / N_SIMDS / (VALU_CLOCK_GHZ * 1e6) for k, q in per.items()}
     total = sum(busy_ms.values())
     return {"bound": "valu issue", "busy_ms_per_step_at_peak_clock": {k: round(v, 3) for k, v in busy_ms.items()},
             "busy_ms_total": round(total, 3), "device_ms": round(gpu_ms, 3), "frac": round(total / gpu_ms, 4),
-            "clock_ghz": VALU_CLOCK_GHZ, "simds": N_SIMDS,
+            "clock_ghz": VALU_CLOCK_GHZ, "simds": N_SIMDS, "lane_utilisation": lane_util,
+            "stale": manifest().get("csrc_sha") != csrc_sha(),
             "source": {"file": os.path.relpath(path, ROOT), "counter": "SQ_ACTIVE_INST_VALU (quad-cycles per launch, all SIMDs)",
                        "code_commit": json.load(open(path)).get("_code_commit")},
             "note": "replayed from the committed counter pass of this command; extend, shade and shadow only (raygen, compaction and "
@@ -299,6 +329,9 @@ def main():
         ctx.dispatch(layout.make_camera(W, H, frame_index=frame_index, **cam_kw), fps)
         frame_index += fps
 
+    # row indices, the packed send buffer and the root's receive buffers exist before any timed step (shard.StripGather)
+    strip_gather = shard.StripGather(frame, world, rank, strip) if world > 1 and not args.rehearse else None
+
     def gather():
         # the strips accumulate locally; ONE gather assembles the frame after the last frame
         if world > 1 and args.rehearse:
@@ -307,7 +340,7 @@ def main():
             if rank == 0:
                 frame.copy_(host)
         elif world > 1:
-            shard.gather_strips(dist, frame, world, rank, strip)
+            strip_gather.run(dist)
 
     def fence():
         if world > 1:
@@ -379,13 +412,13 @@ def main():
                            st.shade_launches, st.segments, shade_bytes_per_segment(mis, p_record, b0_share))
         shw = kernel_entry("shadow", "shadow (any-hit visibility of the next-event record)", st.shadow_ms, st.shadow_launches,
                            st.shadow_traced, shadow_bytes_per_ray(l_bytes))
-        # The dominant kernel = the one with the most device time on the stream that carries the bounce loop: extend or shade
-        # when the shadow kernel runs beside them on its own stream, any of the three on one stream.
+        # The dominant kernel = the one with the most device time among extend, shade and shadow, whatever stream it ran on
+        # (HIP events on the stream each kernel is launched on; with the shadow kernel on its own stream the three times add
+        # up to more than the dispatch time — see kernel_ms_sum_over_gpu_ms)
         overlapped = bool(mis and (args.overlap is None or args.overlap != 0))
-        cands = [(st.extend_ms, ext), (st.shade_ms, shd)] + ([] if overlapped else [(st.shadow_ms, shw)])
+        cands = [(st.extend_ms, ext), (st.shade_ms, shd), (st.shadow_ms, shw)]
         dom = max((c for c in cands if c[1]), key=lambda c: c[0], default=(0, None))[1]
-        dominant_by = ("most device time among the kernels of the main stream (shadow runs beside them on a second stream)"
-                       if overlapped else "most device time among extend, shade, shadow (one stream)")
+        dominant_by = "most device time among extend, shade and shadow (HIP events on the streams they run on)"
         kernel_ms = {"extend": st.extend_ms, "shade": st.shade_ms, "shadow": st.shadow_ms, "raygen": st.raygen_ms,
                      "compact": st.compact_ms, "accumulate": st.accumulate_ms}
         par = f"{strip}-row strips x{world}"

@@ -153,6 +153,11 @@ int ptmi_get_options(const ptmi_ctx *ctx, ptmi_options *opt);
  * frame index incremented by the caller (renderer.ts:453). Asynchronous. */
 int ptmi_dispatch(ptmi_ctx *ctx, const ptmi_camera *camera, uint32_t n_frames);
 int ptmi_synchronize(ptmi_ctx *ctx);
+/* Back-pressure for a caller that enqueues dispatches from a loop without reading results — a preview loop; the reference paces
+ * itself on requestAnimationFrame (renderer.ts:456-473). Blocks until at most max_in_flight of this context's dispatches have
+ * not yet finished on the device and reports how many still are (in_flight may be NULL). max_in_flight = 0xFFFFFFFF only polls.
+ * Independently of this call the library never lets more than 256 dispatches queue up: ptmi_dispatch then waits for the oldest. */
+int ptmi_throttle(ptmi_ctx *ctx, uint32_t max_in_flight, uint32_t *in_flight);
 
 /* ---- output buffer (binding 0) ------------------------------------------ */
 /* width*height float4 (xyz = running mean, w = 0), index y*width+x. Synchronises. */
@@ -216,6 +221,7 @@ int ptmi_multi_dispatch(ptmi_multi *m, const ptmi_camera *camera, uint32_t n_fra
  * their devices; the gather only copies). With one device it is a no-op. */
 int ptmi_multi_gather(ptmi_multi *m);
 int ptmi_multi_synchronize(ptmi_multi *m);
+int ptmi_multi_throttle(ptmi_multi *m, uint32_t max_in_flight, uint32_t *in_flight);   /* ptmi_throttle on every device; reports the maximum */
 /* gather + synchronise + copy device 0's output buffer out (width*height float4) */
 int ptmi_multi_read_output(ptmi_multi *m, float *dst_rgba, size_t n_floats);
 /* resume: the frame is written to every device (each keeps accumulating its rows on top of it) */

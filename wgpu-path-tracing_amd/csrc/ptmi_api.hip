@@ -13,6 +13,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <utility>
 #include <vector>
@@ -78,6 +79,7 @@ struct ptmi_ctx {
     ptmi_stats st{};
     std::vector<EventPair> pending;
     std::vector<hipEvent_t> event_pool;
+    std::deque<hipEvent_t> in_flight;                  // one event per ptmi_dispatch, recorded behind its last kernel (ptmi_throttle)
 };
 
 namespace {
@@ -139,6 +141,22 @@ void drain_completed_events(ptmi_ctx *c) {
     c->pending.resize(n);
     drain_events(c);
     c->pending = std::move(rest);
+}
+
+constexpr size_t kMaxDispatchesInFlight = 256;     // a caller that never throttles or synchronises still cannot queue without bound
+
+// drop the finished dispatches from the front of the list, then wait for the oldest ones until at most `max` are left
+hipError_t throttle(ptmi_ctx *c, size_t max) {
+    while (!c->in_flight.empty() && hipEventQuery(c->in_flight.front()) == hipSuccess) {
+        c->event_pool.push_back(c->in_flight.front()); c->in_flight.pop_front();
+    }
+    (void)hipGetLastError();                          // hipErrorNotReady of the query is not an error
+    while (c->in_flight.size() > max) {
+        hipError_t e = hipEventSynchronize(c->in_flight.front());
+        if (e != hipSuccess) return e;
+        c->event_pool.push_back(c->in_flight.front()); c->in_flight.pop_front();
+    }
+    return hipSuccess;
 }
 
 struct Timed {
@@ -488,6 +506,7 @@ int ptmi_destroy(ptmi_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)sync_all(c);
     drain_events(c);
+    for (hipEvent_t e : c->in_flight) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     for (Lane &ln : c->lanes) {
         free_batch(ln);
@@ -774,9 +793,23 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
         }
     }
     HIP_TRY(c, hipGetLastError());
+    {   // the end of this dispatch on the context's stream (the fold of its last batch): what ptmi_throttle waits for
+        hipEvent_t done = get_event(c);
+        HIP_TRY(c, hipEventRecord(done, c->stream));
+        c->in_flight.push_back(done);
+        if (c->in_flight.size() > kMaxDispatchesInFlight) HIP_TRY(c, throttle(c, kMaxDispatchesInFlight));
+    }
     c->st.paths += npix * n_frames;
     c->st.frames += n_frames;
     c->st.dispatches += 1;
+    return PTMI_OK;
+}
+
+int ptmi_throttle(ptmi_ctx *c, uint32_t max_in_flight, uint32_t *in_flight) {
+    if (!c) return PTMI_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, throttle(c, max_in_flight));
+    if (in_flight) *in_flight = (uint32_t)c->in_flight.size();
     return PTMI_OK;
 }
 
@@ -785,6 +818,7 @@ int ptmi_synchronize(ptmi_ctx *c) {
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, sync_all(c));
     drain_events(c);
+    HIP_TRY(c, throttle(c, 0));
     return PTMI_OK;
 }
 

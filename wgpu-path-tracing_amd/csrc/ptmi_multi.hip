@@ -343,6 +343,19 @@ int ptmi_multi_synchronize(ptmi_multi *m) {
     return PTMI_OK;
 }
 
+int ptmi_multi_throttle(ptmi_multi *m, uint32_t max_in_flight, uint32_t *in_flight) {
+    if (!m) return PTMI_E_INVALID;
+    uint32_t worst = 0;
+    for (size_t i = 0; i < m->ctx.size(); i++) {
+        uint32_t n = 0;
+        int rc = ptmi_throttle(m->ctx[i], max_in_flight, &n);
+        if (rc) return cfail(m, (int)i, rc, "ptmi_throttle");
+        worst = std::max(worst, n);
+    }
+    if (in_flight) *in_flight = worst;
+    return PTMI_OK;
+}
+
 int ptmi_multi_read_output(ptmi_multi *m, float *dst, size_t n_floats) {
     if (!m || !dst) return PTMI_E_INVALID;
     if (m->gathered != m->dispatched) { int rc = ptmi_multi_gather(m); if (rc) return rc; }

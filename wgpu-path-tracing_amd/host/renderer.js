@@ -7,7 +7,16 @@
  *
  *   createBuffers + createBindGroups (renderer.ts:242-355, :368-381) -> uploadScene / uploadAtlas / resize
  *   updateCamera                      (renderer.ts:403-413)          -> packCamera (96-byte uniform)
- *   compute pass dispatch             (renderer.ts:421-431)          -> addon.dispatch(ctx, camera, 1)
+ *   compute pass dispatch             (renderer.ts:421-431)          -> addon.dispatch(ctx, camera, frames)
+ *
+ * options.devices = [ordinal, ...] puts several GPUs of the node behind the same Renderer (include/ptmi.h ptmi_multi_*): the
+ * frame's rows are dealt out as interleaved strips, every device accumulates its own, and the frame is assembled on the first
+ * device by one RCCL gather — when it is read (readOutput / blit), and every options.gatherEvery frames for a preview.
+ *
+ * The frame loop (start) paces itself: the reference's is paced by requestAnimationFrame (renderer.ts:456-473); here a tick
+ * first waits until at most one earlier dispatch is unfinished (two in flight with the new one), and while the camera stands
+ * still it doubles the frames per dispatch up to options.maxFramesPerTick (64) — ptmi_dispatch(camera, n) IS n single-frame
+ * dispatches (include/ptmi.h), so the image is the reference's, at the rate of large batches; any camera change drops to 1.
  *
  * The blit pass, tweakpane stats and the DOM controller are out of scope (SURVEY.md §8).
  * Plain JavaScript (Node >= 12: no optional chaining), typed by index.d.ts.
@@ -24,10 +33,28 @@ function loadAddon() {
 
 var MAX_FRAMES = -1;                       // renderer.ts:16
 
+// the addon's single-device and multi-device entry points under one set of names
+function deviceApi(addon, devices, loopback) {
+  if (!devices) return { multi: false, create: function (d) { return addon.create(d); }, destroy: addon.destroy,
+    uploadScene: addon.uploadScene, uploadAtlas: addon.uploadAtlas, resize: addon.resize, setOptions: addon.setOptions,
+    dispatch: addon.dispatch, synchronize: addon.synchronize, throttle: addon.throttle, readOutput: addon.readOutput,
+    writeOutput: addon.writeOutput, blit: addon.blit, getStats: addon.getStats, gather: function () {} };
+  return { multi: true, create: function () { return addon.multiCreate(devices, loopback ? 1 : 0); }, destroy: addon.multiDestroy,
+    uploadScene: addon.multiUploadScene, uploadAtlas: addon.multiUploadAtlas, resize: addon.multiResize,
+    setOptions: addon.multiSetOptions, dispatch: addon.multiDispatch, synchronize: addon.multiSynchronize,
+    throttle: addon.multiThrottle, readOutput: addon.multiReadOutput, writeOutput: addon.multiWriteOutput, blit: addon.multiBlit,
+    getStats: addon.multiGetStats, gather: addon.multiGather };
+}
+
 function Renderer(options) {
   options = options || {};
   this.addon = loadAddon();
-  this.ctx = this.addon.create(options.device || 0);   // throws without a gfx950 device: there is no CPU path
+  this.api = deviceApi(this.addon, options.devices, options.loopback);
+  this.ctx = this.api.create(options.device || 0);     // throws without a gfx950 device: there is no CPU path
+  this.gatherEvery = options.gatherEvery || 0;          // several devices: assemble the frame every so many frames (0: when it is read)
+  this.sinceGather = 0;
+  this.maxFramesPerTick = options.maxFramesPerTick || 64;
+  this.framesPerTick = 1;
   this.width = options.width || 800;
   this.height = options.height || 600;
   this.frameIndex = 0;
@@ -37,8 +64,8 @@ function Renderer(options) {
   this.sceneLoaded = false;
   this.cameraBytes = new ArrayBuffer(pack.CAMERA_SIZE);
   this.setupCamera();
-  this.addon.resize(this.ctx, this.width, this.height);
-  if (options.options) this.addon.setOptions(this.ctx, options.options);
+  this.api.resize(this.ctx, this.width, this.height);
+  if (options.options) this.api.setOptions(this.ctx, options.options);
 }
 
 /** renderer.ts:136-150 */
@@ -72,9 +99,9 @@ Renderer.prototype.loadModel = function (model, atlas) {
     } else {
       blobs = pack.packScene(model);
     }
-    self.addon.uploadScene(self.ctx, blobs.triangles, blobs.materials, blobs.bvhNodes, blobs.lights);
-    if (atlas) self.addon.uploadAtlas(self.ctx, atlas.data, atlas.width, atlas.height, atlas.format || 1);
-    else self.addon.uploadAtlas(self.ctx, null, 0, 0, 0);
+    self.api.uploadScene(self.ctx, blobs.triangles, blobs.materials, blobs.bvhNodes, blobs.lights);
+    if (atlas) self.api.uploadAtlas(self.ctx, atlas.data, atlas.width, atlas.height, atlas.format || 1);
+    else self.api.uploadAtlas(self.ctx, null, 0, 0, 0);
     self.sceneLoaded = true;
     self.resetOutputBuffer(false);
     resolve();
@@ -85,6 +112,7 @@ Renderer.prototype.loadModel = function (model, atlas) {
 Renderer.prototype.resetOutputBuffer = function (restart) {
   this.frameIndex = 0;
   this.camera.frameIndex = 0;
+  this.framesPerTick = 1;                   // the picture changed: back to one frame per tick, for the shortest latency
   if (restart !== false && this.timer === null && this.sceneLoaded) this.start();
 };
 
@@ -98,8 +126,12 @@ Renderer.prototype.updateCamera = function () {
 Renderer.prototype.renderFrame = function (frames) {
   frames = frames || 1;
   this.updateCamera();
-  this.addon.dispatch(this.ctx, this.cameraBytes, frames);
+  this.api.dispatch(this.ctx, this.cameraBytes, frames);
   this.frameIndex += frames;
+  if (this.api.multi && this.gatherEvery > 0) {
+    this.sinceGather += frames;
+    if (this.sinceGather >= this.gatherEvery) { this.api.gather(this.ctx); this.sinceGather = 0; }
+  }
 };
 
 /** renderer.ts:456-473 — requestAnimationFrame becomes setImmediate */
@@ -110,8 +142,15 @@ Renderer.prototype.start = function () {
     var now = Date.now();
     var dt = (now - self.lastTime) / 1000;
     self.lastTime = now;
-    for (var i = 0; i < self.onUpdateTasks.length; i++) self.onUpdateTasks[i](dt);
-    if (MAX_FRAMES === -1 || self.frameIndex < MAX_FRAMES) self.renderFrame();
+    for (var i = 0; i < self.onUpdateTasks.length; i++) self.onUpdateTasks[i](dt);      // may move the camera: framesPerTick = 1
+    if (self.timer === null) return;        // an update task stopped the loop
+    if (MAX_FRAMES === -1 || self.frameIndex < MAX_FRAMES) {
+      self.api.throttle(self.ctx, 1);       // back-pressure: at most one earlier dispatch unfinished, two in flight with this one
+      var n = self.framesPerTick;
+      if (MAX_FRAMES !== -1) n = Math.min(n, MAX_FRAMES - self.frameIndex);
+      self.renderFrame(n);
+      self.framesPerTick = Math.min(self.framesPerTick * 2, self.maxFramesPerTick);     // still camera: larger batches
+    }
     if (self.timer !== null) self.timer = setImmediate(animate);
   };
   this.timer = setImmediate(animate);
@@ -124,7 +163,7 @@ Renderer.prototype.stop = function () {
 /** renderer.ts:482-494 */
 Renderer.prototype.destroy = function () {
   this.stop();
-  if (this.ctx) { this.addon.destroy(this.ctx); this.ctx = null; }
+  if (this.ctx) { this.api.destroy(this.ctx); this.ctx = null; }
 };
 
 /** renderer.ts:496-510 */
@@ -133,7 +172,8 @@ Renderer.prototype.resize = function (width, height) {
   this.camera.aspect = width / height;
   this.camera.width = width; this.camera.height = height;
   this.frameIndex = 0;
-  this.addon.resize(this.ctx, width, height);
+  this.framesPerTick = 1;
+  this.api.resize(this.ctx, width, height);
 };
 
 /** renderer.ts:152-170 */
@@ -166,19 +206,22 @@ Renderer.prototype.rotateCamera = function (yaw, pitch) {
 /** Output buffer (binding 0): width*height float4, row 0 = image bottom. Synchronises. */
 Renderer.prototype.readOutput = function () {
   var out = new Float32Array(this.width * this.height * 4);
-  this.addon.readOutput(this.ctx, out);
+  this.api.readOutput(this.ctx, out);
   return out;
 };
 
 /** The reference's blit pass (renderer.ts:434-449, blit.wgsl): tone-mapped 8-bit canvas, row 0 = top. */
 Renderer.prototype.blit = function () {
   var out = new Uint8Array(this.width * this.height * 4);
-  this.addon.blit(this.ctx, out);
+  this.api.blit(this.ctx, out);
   return out;
 };
 
-Renderer.prototype.setOptions = function (o) { this.addon.setOptions(this.ctx, o); };
-Renderer.prototype.getStats = function () { return this.addon.getStats(this.ctx); };
+Renderer.prototype.setOptions = function (o) { this.api.setOptions(this.ctx, o); };
+Renderer.prototype.getStats = function () { return this.api.getStats(this.ctx); };
+/** several devices: assemble the frame on the first one now (readOutput / blit do it themselves) */
+Renderer.prototype.gather = function () { this.api.gather(this.ctx); this.sinceGather = 0; };
+Renderer.prototype.synchronize = function () { this.api.synchronize(this.ctx); };
 
 /** renderer.ts:513-558 without the canvas: create, load, (optionally) start; options.input (an event source,
  *  see controller.js) gets a Controller whose update runs every frame, like renderer.ts:554-555 */

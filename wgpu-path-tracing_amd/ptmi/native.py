@@ -22,7 +22,7 @@ EXPORTS = [
     "ptmi_synchronize", "ptmi_read_output", "ptmi_write_output", "ptmi_output_device_ptr",
     "ptmi_bind_output_device", "ptmi_set_stream", "ptmi_blit", "ptmi_get_stats", "ptmi_reset_stats",
     "ptmi_debug_raygen", "ptmi_debug_intersect", "ptmi_debug_occluded", "ptmi_debug_math", "ptmi_debug_exact_math", "ptmi_get_size",
-    "ptmi_debug_image_stats",
+    "ptmi_debug_image_stats", "ptmi_throttle", "ptmi_multi_throttle",
     "ptmi_multi_create", "ptmi_multi_destroy", "ptmi_multi_last_error", "ptmi_multi_count", "ptmi_multi_context",
     "ptmi_multi_upload_scene", "ptmi_multi_upload_atlas", "ptmi_multi_resize", "ptmi_multi_set_options", "ptmi_multi_get_options",
     "ptmi_multi_dispatch", "ptmi_multi_gather", "ptmi_multi_synchronize", "ptmi_multi_read_output", "ptmi_multi_write_output",
@@ -109,6 +109,8 @@ def load():
         L.ptmi_debug_occluded.argtypes = [vp, u32, vp, vp, vp, vp]
         L.ptmi_debug_math.argtypes = [vp, ctypes.c_int, u32, vp, vp, vp, vp]
         L.ptmi_debug_exact_math.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
+        L.ptmi_throttle.argtypes = [vp, u32, ctypes.POINTER(ctypes.c_uint32)]
+        L.ptmi_multi_throttle.argtypes = [vp, u32, ctypes.POINTER(ctypes.c_uint32)]
         L.ptmi_multi_last_error.restype = ctypes.c_char_p
         L.ptmi_multi_last_error.argtypes = [vp]
         L.ptmi_multi_context.restype = vp
@@ -217,6 +219,12 @@ class Context:
 
     def synchronize(self):
         self._ck(self.L.ptmi_synchronize(self.h))
+
+    def throttle(self, max_in_flight=0xFFFFFFFF):
+        """Blocks until at most max_in_flight dispatches are unfinished (default: only polls); returns how many are."""
+        n = ctypes.c_uint32(0)
+        self._ck(self.L.ptmi_throttle(self.h, max_in_flight, ctypes.byref(n)))
+        return int(n.value)
 
     def read_output(self):
         out = np.empty((self.height, self.width, 4), np.float32)
