@@ -90,7 +90,13 @@ typedef struct ptmi_options {
                                    index) rule, so results are unchanged. 0 = library default, 1 = off, 2 = on where it fits */
     uint32_t tails;             /* how the last bounces' small queues are traced: 0 = library default, 1 = every kernel its own launch,
                                    2 = `shadow` of bounce b and `extend` of bounce b + 1 share ONE traversal launch (results unchanged) */
-    uint32_t reserved[6];
+    uint32_t state;             /* where a path's ray state (origin + RNG, direction, throughput) lives between bounces: 1 = in place,
+                                   indexed by path id for the whole batch (by bounce 4 the survivors are 7 % of the paths: every read
+                                   fetches a memory sector for 16 bytes of it); 2 = it follows the queue: `shade` of bounce b writes the
+                                   survivors' state at their slot of bounce b's queue into a second set of buffers (+ the path id, for
+                                   the radiance), the next queue lists those slots, so the next bounce reads it at the density of ONE
+                                   bounce's survival rate. Same arithmetic, same results. 0 = library default */
+    uint32_t reserved[5];
 } ptmi_options;
 
 typedef struct ptmi_stats {
@@ -122,6 +128,8 @@ typedef struct ptmi_stats {
     uint32_t worklist_used;     /* of the last dispatch / per-stage call: bit 0 the closest-hit kernel, bit 1 the any-hit kernel ran the
                                    per-wave work list (ptmi_options.worklist) */
     uint32_t tails_used;        /* ... 1: shadow(b) and extend(b + 1) shared one traversal launch (ptmi_options.tails) */
+    uint32_t state_used;        /* ... 1: ray state in place by path id, 2: it followed the queue (ptmi_options.state) */
+    uint32_t reserved_stats;
 } ptmi_stats;
 
 /* ---- lifetime ----------------------------------------------------------- */
@@ -245,7 +253,9 @@ int ptmi_debug_raygen(ptmi_ctx *ctx, const ptmi_camera *camera, uint32_t n, cons
 /* extend kernel (pt.wgsl:248-296) on caller rays: t = -1 / tri = 0xFFFFFFFF on miss. */
 int ptmi_debug_intersect(ptmi_ctx *ctx, uint32_t n, const float *o3, const float *d3,
                          float *t, uint32_t *tri, float *u, float *v);
-/* shadow kernel predicate (pt.wgsl:394/423/465); dist[i] < 0 = directional. */
+/* shadow kernel predicate (pt.wgsl:394/423/465); dist[i] < 0 = directional light (any hit occludes). Every negative value
+ * means that: the library normalises them to -1 before the kernel sees them (inside a dispatch, -2 marks the record of an
+ * emissive hit, which is added without a traversal — never a value a caller can inject here). */
 int ptmi_debug_occluded(ptmi_ctx *ctx, uint32_t n, const float *o3, const float *d3,
                         const float *dist, uint8_t *occluded);
 /* Host-only (no context, no device): builds the traversal image ptmi_upload_scene would build and reports on it.

@@ -1,0 +1,89 @@
+"""GPU parity of ptmi_options.state = 2 (the ray state follows the queue): `shade` of bounce b writes the survivors' origin / RNG
+state, direction and throughput at their slot of bounce b's queue into the other of two buffer sets, the next queue lists those
+slots, and the radiance stays addressed by the path id each slot carries. Only WHERE the state is kept changes — every RNG
+draw, every counter and every radiance bit must equal the oracle's, with the shadow stream on or off, in several batches, with
+ray sorting, on two lanes, for 1 ... 8 bounces, from LDS and from global memory.
+Reference: the bounce loop of src/shader/pt.wgsl:642-706 (one thread keeps its ray in registers; here it moves between buffers)."""
+import numpy as np
+import pytest
+
+from ptmi import layout
+from test_gpu_parity import assert_same_floats
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def st_ctx(gpu_ctx):
+    from ptmi import native
+    gpu_ctx.set_options(state=2)
+    yield gpu_ctx
+    gpu_ctx.set_options(state=0, traversal=native.TRAVERSAL_AUTO, cull=1, keep_reference_tree=0, overlap=2, frames_per_batch=0,
+                        max_bounces=8, do_mis=1, ray_sort=2, tile_y0=0, tile_y1=0, tile_parts=0)
+
+
+@pytest.mark.parametrize("name,W,H,frames,bounces,mis,ap", [
+    ("cornell", 200, 130, 5, 8, 1, 0.001), ("cornell", 64, 64, 4, 4, 0, 0.001), ("cornell", 96, 64, 3, 1, 1, 0.0),
+    ("cornell", 96, 64, 3, 2, 1, 0.0), ("cornell", 96, 64, 3, 3, 1, 0.0), ("cornell_glass", 80, 60, 5, 8, 1, 0.0),
+    ("feature_box", 72, 72, 6, 8, 1, 0.05), ("cornell_spheres", 64, 48, 3, 8, 1, 0.0)])
+def test_state_follows_the_queue_render_parity(st_ctx, oracle, scene_factory, name, W, H, frames, bounces, mis, ap):
+    from ptmi import native
+    sc = scene_factory(name)
+    cam = layout.make_camera(W, H, aperture=ap, focus_distance=2.8)
+    ref, ost = oracle.render(sc, cam, frames, max_bounces=bounces, do_mis=mis)
+    st_ctx.upload_scene(sc)
+    for overlap, fpb, trav, sort in ((1, 0, native.TRAVERSAL_AUTO, 2), (0, 0, native.TRAVERSAL_AUTO, 2), (1, 2, native.TRAVERSAL_GLOBAL, 2),
+                                     (1, 0, native.TRAVERSAL_AUTO, 1), (3, 4, native.TRAVERSAL_AUTO, 2)):
+        st_ctx.resize(W, H)
+        st_ctx.set_options(max_bounces=bounces, do_mis=mis, frames_per_batch=fpb, overlap=overlap, traversal=trav, ray_sort=sort)
+        st_ctx.reset_stats()
+        st_ctx.dispatch(cam, frames)
+        got = st_ctx.read_output()
+        st = st_ctx.stats()
+        assert st.state_used == 2, "the state did not follow the queue"
+        assert (st.segments, st.shadow_rays, st.paths) == (ost.segments, ost.shadow_rays, ost.paths)
+        assert_same_floats(got, ref, f"radiance ({name}, overlap {overlap}, frames_per_batch {fpb}, traversal {trav}, ray_sort {sort})")
+
+
+def test_state_modes_agree_and_switch_within_one_context(st_ctx, oracle, scene_factory):
+    """in place -> following the queue -> in place on one context (the second buffer set is allocated on first use), a resumed
+    accumulation across the switch, and interleaved row strips"""
+    sc = scene_factory("cornell")
+    W, H = 128, 96
+    cam = layout.make_camera(W, H, aperture=0.001, focus_distance=5.0)
+    ref, _ = oracle.render(sc, cam, 6, max_bounces=8, do_mis=1)
+    st_ctx.upload_scene(sc)
+    st_ctx.resize(W, H)
+    st_ctx.set_options(state=1)
+    st_ctx.dispatch(cam, 2)
+    assert st_ctx.stats().state_used == 1
+    st_ctx.set_options(state=2)
+    cam2 = cam.copy(); cam2["frame_index"] = 2
+    st_ctx.dispatch(cam2, 2)
+    assert st_ctx.stats().state_used == 2
+    st_ctx.set_options(state=1, tile_parts=2, tile_part=0, tile_strip=4)
+    cam3 = cam.copy(); cam3["frame_index"] = 4
+    st_ctx.dispatch(cam3, 2)
+    st_ctx.set_options(state=2, tile_parts=2, tile_part=1, tile_strip=4)
+    st_ctx.dispatch(cam3, 2)
+    assert_same_floats(st_ctx.read_output(), ref, "radiance over three dispatches in alternating state modes")
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_state_follows_the_queue_random_scene_fuzz(st_ctx, oracle, seed):
+    from ptmi import scenes
+    sc = scenes.random_soup(60 + seed)
+    W, H, frames = 64, 48, 4
+    cam = layout.make_camera(W, H, aperture=0.02 if seed % 2 else 0.0, focus_distance=2.5)
+    ref, ost = oracle.render(sc, cam, frames, max_bounces=8, do_mis=1)
+    for keep in (0, 1):
+        st_ctx.set_options(keep_reference_tree=keep)
+        st_ctx.upload_scene(sc)
+        st_ctx.resize(W, H)
+        st_ctx.reset_stats()
+        st_ctx.dispatch(cam, frames)
+        got = st_ctx.read_output()
+        st = st_ctx.stats()
+        assert st.state_used == 2
+        assert (st.segments, st.shadow_rays, st.paths) == (ost.segments, ost.shadow_rays, ost.paths)
+        assert_same_floats(got, ref, f"radiance (seed {seed}, keep {keep})")

@@ -177,3 +177,50 @@ def test_strip_rows_partition_and_loopback_gather(H, world):
         frames.append(f)
     got = _LoopbackDist(world).run(frames, strip, lambda d, f, w, r, s: shard.gather_strips(d, f, w, r, s))
     assert torch.equal(got, want)
+
+
+def _strip8_worker(rank, world, port, H, W, q):
+    sys.path.insert(0, os.path.join(ROOT, "wgpu-path-tracing_amd"))
+    import torch
+    import torch.distributed as dist
+    from ptmi import shard as sh
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        strip = sh.strip_rows_for(H, world)
+        rows = sh.strip_rows(H, world, rank, strip)
+        frame = torch.zeros((H, W, 4), dtype=torch.float32)
+        g = sh.StripGather(frame, world, rank, strip)          # built once, outside the loop, as bench.py does
+        ok = True
+        for rnd in (1, 2):                                     # two gathers through the same buffers (warm-up + timed region)
+            frame.zero_()
+            for y in rows:                                     # a value that names (round, row, column, channel)
+                frame[y] = (rnd * 1e6 + y * 16 + torch.arange(W * 4, dtype=torch.float32).reshape(W, 4) % 16)
+            g.run(dist)
+            dist.barrier()
+            if rank == 0:
+                want = (rnd * 1e6 + torch.arange(H, dtype=torch.float32).reshape(H, 1, 1) * 16
+                        + (torch.arange(W * 4, dtype=torch.float32).reshape(1, W, 4) % 16))
+                ok = ok and bool(torch.equal(frame, want))
+        if rank == 0:
+            q.put((ok, strip, len(rows)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_gloo_strip_gather_of_the_2160_row_frame():
+    """`bench.py --config 4 --gpus 8` end to end on the CPU: 2160 rows are not a whole number of rounds of 8 x 4 rows, so the
+    shard unit becomes 3-row strips (shard.strip_rows_for); eight gloo ranks each fill their 270 rows, ONE StripGather per rank
+    runs twice, and the root must hold every row of the frame, in place, both times."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_strip8_worker, args=(r, 8, port, 2160, 6, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    ok, strip, n_rows = q.get(timeout=10)
+    assert (ok, strip, n_rows) == (True, 3, 270)

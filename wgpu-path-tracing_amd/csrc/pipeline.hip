@@ -192,7 +192,11 @@ __global__ __launch_bounds__(TILE_WORDS) void k_scatter2(uint32_t tiles, const u
 // d.x, d.y, d.z), each group in ascending slot order. A wave of the next traversal then holds rays of one octant whose
 // path ids lie within ~1024 of each other (so their state is still read from a 16-KB neighbourhood). The set of rays, their
 // arithmetic and their results do not depend on the order in which the queue lists them.
-constexpr int SORT_WINDOW = 16;          // words per window; 4 windows per wave, 16 per tile
+constexpr int SORT_WINDOW = 16;          // words per window; 4 windows per wave, TILE_WORDS / 16 per tile
+// static LDS of k_scatter_sorted: two [TILE_WORDS][8] tables + the wave totals. At 1024 words that is 65.6 KB — more than the 64 KB
+// other targets allow, fine on gfx950's 160 KB; PT_TILE_WORDS is a -D parameter, so the bound is checked here
+static_assert(TILE_WORDS % 64 == 0 && TILE_WORDS <= 1024, "a tile is a workgroup of whole waves, at most 1024 threads");
+static_assert(2u * TILE_WORDS * 8u * sizeof(uint32_t) + (TILE_WAVES + 1u) * sizeof(uint32_t) <= 160u * 1024u, "k_scatter_sorted's LDS tables");
 
 __global__ __launch_bounds__(TILE_WORDS) void k_scatter_sorted(const uint32_t *__restrict__ count_ptr,
                                                                const uint32_t *__restrict__ queue,

@@ -99,6 +99,14 @@ struct ShadeParams {
                                         //    that `shadow` adds like an unoccluded light sample — all additions to L then happen in
                                         //    that one kernel, in bounce order, and `shadow` can run beside the next bounce's kernels.
                                         //    stats[3] += such records (they are not shadow rays)
+    // STATE FOLLOWS THE QUEUE (ptmi_options.state = 2; all NULL: the state stays in place, at the path's id). The state this
+    // launch READS is the DevPaths argument, at index q = queue[slot]; the survivors' new state goes to these buffers at index
+    // `slot` — dense in this bounce's queue — and the next queue lists slots instead of path ids, so the next bounce gathers its
+    // rays at the density of one bounce's survival rate (0.5 - 0.8) instead of the whole path's (0.07 by bounce 4 on Cornell).
+    // The radiance stays indexed by path id: pid_in[q] is the path whose state sits at q (NULL: q itself), pid_out[slot] its copy
+    // for the next bounce (NULL: not needed, slot is the path id — bounce 0).
+    float4 *O_out, *D_out; float2 *C_out;
+    const uint32_t *pid_in; uint32_t *pid_out;
 };
 
 enum { PT_VARIANT_GLOBAL = 1, PT_VARIANT_LDS = 2, PT_VARIANT_LDS_NODES = 3 };

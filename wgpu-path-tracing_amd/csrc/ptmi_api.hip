@@ -31,6 +31,8 @@ constexpr size_t kMaxPendingEvents = 4096;        // a caller that never synchro
 struct Lane {
     size_t cap = 0;
     DevPaths paths{};
+    // second set of ray-state buffers and the path ids of both sets (ptmi_options.state = 2: the state follows the queue)
+    float4 *O2 = nullptr, *D2 = nullptr; float2 *C2 = nullptr; uint32_t *pid[2] = {nullptr, nullptr};
     float2 *hits = nullptr;
     DevShadow sh[2]{};                                 // shadow records, double-buffered by bounce parity (overlap >= 1)
     uint32_t *queue[2] = {nullptr, nullptr}, *sq[2] = {nullptr, nullptr};
@@ -87,6 +89,9 @@ namespace {
 constexpr int kStatsWords = 8 + 64;
 constexpr int kShadowCount = 72;          // slot of the shadow-queue length in ctx->counts (80 words)
 constexpr size_t kLdsMax = 160 * 1024;
+#ifndef PT_STATE_DEFAULT
+#define PT_STATE_DEFAULT 1             /* what ptmi_options.state = 0 means: 1 in place, 2 the state follows the queue (measured: profiles/README.md) */
+#endif
 #ifndef PT_WORKLIST_DEFAULT
 #define PT_WORKLIST_DEFAULT 0          /* what ptmi_options.worklist = 0 means (measured: profiles/README.md) */
 #endif
@@ -175,6 +180,7 @@ struct Timed {
 
 void free_batch(Lane &ln) {
     dfree(ln.paths.O); dfree(ln.paths.D); dfree(ln.paths.C); dfree(ln.paths.L);
+    dfree(ln.O2); dfree(ln.D2); dfree(ln.C2); dfree(ln.pid[0]); dfree(ln.pid[1]);
     dfree(ln.hits);
     for (int k = 0; k < 2; k++) { dfree(ln.sh[k].SO); ln.sh[k].SD = nullptr; ln.sh[k].SC = nullptr; dfree(ln.sq[k]); }
     dfree(ln.queue[0]); dfree(ln.queue[1]); dfree(ln.alive); dfree(ln.shadowm); dfree(ln.octm); dfree(ln.word_off); dfree(ln.d_occ);
@@ -192,11 +198,14 @@ hipError_t sync_all(ptmi_ctx *c) {
     return e;
 }
 
-// bytes of device memory a path of a batch takes in ensure_capacity (state 56 + hit 8 + 2 x (record 44 + index 4) + 2 queues + masks)
+// bytes of device memory a path of a batch takes in ensure_capacity (state 56 + hit 8 + 2 x (record 44 + index 4) + 2 queues + masks;
+// with the state following the queue a second set of ray state, 40, and two path-id lists)
 constexpr size_t kBytesPerPath = 16 + 16 + 8 + 16 + 8 + 2 * (16 + 16 + sizeof(rgb_sc) + 4) + 2 * 4 + 1 + 1;
+constexpr size_t kBytesPerPathState2 = 16 + 16 + 8 + 2 * 4;
 
-int ensure_capacity(ptmi_ctx *c, Lane &ln, size_t n) {
-    if (n <= ln.cap) return PTMI_OK;
+int ensure_capacity(ptmi_ctx *c, Lane &ln, size_t n, bool state2) {
+    if (n <= ln.cap && (!state2 || ln.O2)) return PTMI_OK;
+    if (n < ln.cap) n = ln.cap;
     HIP_TRY(c, sync_all(c));
     free_batch(ln);
     size_t cap = (n + 1023) & ~(size_t)1023;
@@ -210,6 +219,7 @@ int ensure_capacity(ptmi_ctx *c, Lane &ln, size_t n) {
         return fail(c, PTMI_E_HIP, "hipMalloc of %zu bytes for a batch of %zu paths failed: %s", (size_t)(bytes), cap, hipGetErrorString(e_)); } } while (0)
     ALLOC(ln.paths.O, cap * 16); ALLOC(ln.paths.D, cap * 16);
     ALLOC(ln.paths.C, cap * 8); ALLOC(ln.paths.L, cap * 16);      // room for either stride
+    if (state2) { ALLOC(ln.O2, cap * 16); ALLOC(ln.D2, cap * 16); ALLOC(ln.C2, cap * 8); ALLOC(ln.pid[0], cap * 4); ALLOC(ln.pid[1], cap * 4); }
     ALLOC(ln.hits, cap * 8);
     for (int k = 0; k < 2; k++) {
         ALLOC(ln.sh[k].SO, cap * (16 + 16 + sizeof(rgb_sc)));
@@ -637,6 +647,7 @@ int ptmi_set_options(ptmi_ctx *c, const ptmi_options *o) {
     if (o->overlap > 3) return fail(c, PTMI_E_INVALID, "unknown overlap %u", o->overlap);
     if (o->worklist > 2) return fail(c, PTMI_E_INVALID, "unknown worklist %u", o->worklist);
     if (o->tails > 2) return fail(c, PTMI_E_INVALID, "unknown tails %u", o->tails);
+    if (o->state > 2) return fail(c, PTMI_E_INVALID, "unknown state %u", o->state);
     c->opt = *o;
     return PTMI_OK;
 }
@@ -661,6 +672,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     // ~128 Mi paths, ~23 GB of state: the last bounces' small queues cost a fixed ~3 ms per batch, so fewer, larger batches
     // (measured at 1080p, Msamples/s: 32 frames 8 920, 64 frames 9 150 - 9 275, 128 frames 9 270 - 9 310)
     const bool auto_F = F == 0;
+    const bool state2 = (c->opt.state ? c->opt.state : (uint32_t)PT_STATE_DEFAULT) == 2u;
     if (auto_F) {
         F = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, (128ull << 20) / npix));
         // ... but never more than the device has room for: several contexts may share one device (ranks rehearsed on one GPU, a
@@ -668,9 +680,10 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
         // Room = free memory + what this context's lanes already hold, less a tenth for the rest (spill areas, blit staging).
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const uint64_t held = (uint64_t)(c->lanes[0].cap + c->lanes[1].cap) * kBytesPerPath;
+            const uint64_t held = (uint64_t)c->lanes[0].cap * (kBytesPerPath + (c->lanes[0].O2 ? kBytesPerPathState2 : 0)) +
+                                  (uint64_t)c->lanes[1].cap * (kBytesPerPath + (c->lanes[1].O2 ? kBytesPerPathState2 : 0));
             const uint64_t room = (uint64_t)((double)(free_b + held) * 0.9);
-            const uint64_t fit = room / (npix * kBytesPerPath);
+            const uint64_t fit = room / (npix * (kBytesPerPath + (state2 ? kBytesPerPathState2 : 0)));
             F = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(F, fit));
         }
     }
@@ -696,7 +709,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     if (two_lanes != c->last_two_lanes) { HIP_TRY(c, sync_all(c)); c->last_two_lanes = two_lanes; }     // lane 0 changes streams
     for (;;) {
         rc = PTMI_OK;
-        for (int k = 0; k < (two_lanes ? 2 : 1) && rc == PTMI_OK; k++) rc = ensure_capacity(c, c->lanes[k], (size_t)(npix * Fsub));
+        for (int k = 0; k < (two_lanes ? 2 : 1) && rc == PTMI_OK; k++) rc = ensure_capacity(c, c->lanes[k], (size_t)(npix * Fsub), state2);
         if (rc == PTMI_OK) break;
         // out of device memory with a batch size the library chose: halve it and try again (hipMemGetInfo is a snapshot; another
         // context may have allocated since). A size the caller asked for fails loudly.
@@ -716,6 +729,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     c->st.traversal_used = cfg0.variant == PT_VARIANT_GLOBAL ? PTMI_TRAVERSAL_GLOBAL : PTMI_TRAVERSAL_LDS;
     c->st.frames_per_batch_used = Fsub;
     c->st.worklist_used = (cfg0.worklist ? 1u : 0u) | ((nee && cfg_shadow0.worklist) ? 2u : 0u);
+    c->st.state_used = state2 ? 2u : 1u;
     c->st.radiance_stride_bytes = 4u * (PT_L_STRIDE ? (uint32_t)PT_L_STRIDE : ((cfg0.quantized || cfg_shadow0.quantized) ? 4u : 3u));
     const int blocks = c->n_cu * 8;
 #ifndef PT_SHADE_WGS_PER_CU
@@ -749,19 +763,34 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
             { Timed t(c, 4, t3, ms); pt_launch_raygen(ms, blocks, *cam, band, frame0, fb, ln.paths, &ln.counts[0]); }
             int cur = 0;
             const uint32_t mid_bounce = std::min(3u, maxb - 1u);
+            // state = 2: the rays of bounce b live in set A (ln.paths) for b <= 1 and odd b, in set B (O2, D2, C2) for even b >= 2,
+            // at the index the queue gives: the path id up to bounce 1 (bounce 0 writes in place: its slots ARE the path ids), from
+            // then on the ray's slot in the previous bounce's queue. shade(b) reads set(b) and writes set(b + 1) at its own slots.
+            DevPaths setA = ln.paths, setB = ln.paths;
+            setB.O = ln.O2; setB.D = ln.D2; setB.C = ln.C2;
             for (uint32_t b = 0; b < maxb; b++) {
                 const uint32_t *q = b == 0 ? nullptr : ln.queue[cur];      // bounce 0: slot i holds path i
                 const int par = side ? (int)(b & 1u) : 0;
-                { Timed t(c, 1, t2, ms); pt_launch_extend(ms, blocks, cfg, c->sc, ln.paths, q, &ln.counts[b], ln.hits); }
+                const bool in_b = state2 && b >= 2u && !(b & 1u), out_b = state2 && b >= 1u && (b & 1u);    // set B read / written
+                const DevPaths &pin = in_b ? setB : setA, &pout = out_b ? setB : setA;
+                ShadeParams shp{b, maxb, c->opt.do_mis, c->d_stats, nullptr, (uint32_t)ln.mask_words, side ? 1u : 0u,
+                                nullptr, nullptr, nullptr, nullptr, nullptr};
+                if (state2) {
+                    shp.O_out = pout.O; shp.D_out = pout.D; shp.C_out = pout.C;
+                    shp.pid_in = b >= 2u ? ln.pid[in_b ? 1 : 0] : nullptr;
+                    shp.pid_out = b >= 1u ? ln.pid[out_b ? 1 : 0] : nullptr;
+                }
+                const uint32_t *cq = state2 ? nullptr : q;                 // what compaction lists: the slots themselves / their path ids
+                { Timed t(c, 1, t2, ms); pt_launch_extend(ms, blocks, cfg, c->sc, pin, q, &ln.counts[b], ln.hits); }
                 const bool last = b + 1 == maxb;
                 uint64_t *octm = (sort && !last) ? ln.octm : nullptr;
                 if (side && b >= 2) HIP_TRY(c, hipStreamWaitEvent(ms, ln.ev_shadow[par], 0));      // its records are read
+                shp.octant_masks = octm;
                 { Timed t(c, 2, t3, ms);
                   (c->opt.perf_mode ? pt_launch_shade_fast : pt_launch_shade)(
-                      ms, shade_blocks, c->sc, ln.paths, q, &ln.counts[b], ln.hits, ln.sh[par], ln.alive, ln.shadowm,
-                      ShadeParams{b, maxb, c->opt.do_mis, c->d_stats, octm, (uint32_t)ln.mask_words, side ? 1u : 0u}); }
+                      ms, shade_blocks, c->sc, pin, q, &ln.counts[b], ln.hits, ln.sh[par], ln.alive, ln.shadowm, shp); }
                 { Timed t(c, 5, t3, ms);
-                  pt_launch_compact(ms, tiles, q, &ln.counts[b], ln.alive, nee ? ln.shadowm : nullptr,
+                  pt_launch_compact(ms, tiles, cq, &ln.counts[b], ln.alive, nee ? ln.shadowm : nullptr,
                                     ln.word_off, ln.queue[cur ^ 1], &ln.counts[b + 1], ln.sq[par], &ln.counts[kShadowCount + par],
                                     c->d_stats, b, last ? 0 : 1, octm, (uint32_t)ln.mask_words); }
                 if (two_lanes && b == mid_bounce) { HIP_TRY(c, hipEventRecord(ln.ev_mid, ms)); ln.mid_recorded = true; }
@@ -927,7 +956,7 @@ int ptmi_debug_raygen(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n, const uin
     HIP_TRY(c, hipSetDevice(c->device));
     Lane &ln = c->lanes[0];                          // the per-stage entry points use the first lane, on the context's stream
     HIP_TRY(c, sync_all(c));
-    int rc = ensure_capacity(c, ln, n);
+    int rc = ensure_capacity(c, ln, n, false);
     if (rc) return rc;
     uint32_t *dx = ln.queue[0], *dy = ln.queue[1], *df = reinterpret_cast<uint32_t *>(ln.hits);
     HIP_TRY(c, hipMemcpyAsync(dx, xs, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
@@ -955,7 +984,7 @@ int ptmi_debug_intersect(ptmi_ctx *c, uint32_t n, const float *o3, const float *
     HIP_TRY(c, hipSetDevice(c->device));
     Lane &ln = c->lanes[0];                          // the per-stage entry points use the first lane, on the context's stream
     HIP_TRY(c, sync_all(c));
-    rc = ensure_capacity(c, ln, n);
+    rc = ensure_capacity(c, ln, n, false);
     if (rc) return rc;
     rc = upload_rays(c, n, o3, d3, nullptr, ln.paths.O, ln.paths.D);
     if (rc) return rc;
@@ -988,9 +1017,14 @@ int ptmi_debug_occluded(ptmi_ctx *c, uint32_t n, const float *o3, const float *d
     HIP_TRY(c, hipSetDevice(c->device));
     Lane &ln = c->lanes[0];                          // the per-stage entry points use the first lane, on the context's stream
     HIP_TRY(c, sync_all(c));
-    rc = ensure_capacity(c, ln, n);
+    rc = ensure_capacity(c, ln, n, false);
     if (rc) return rc;
-    rc = upload_rays(c, n, o3, d3, dist, ln.sh[0].SO, ln.sh[0].SD);
+    {   // every negative distance means "directional light" (ptmi.h). Inside the library -2 is the record of an emissive hit
+        // (nothing to trace, traverse.hip ShadowIO::fetch): a caller's -2 must not be read as that, so negatives travel as -1
+        std::vector<float> dn(dist, dist + n);
+        for (float &x : dn) if (x < 0.0f) x = -1.0f;
+        rc = upload_rays(c, n, o3, d3, dn.data(), ln.sh[0].SO, ln.sh[0].SD);
+    }
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(&ln.counts[0], &n, 4, hipMemcpyHostToDevice, c->stream));
     TraverseConfig cfg = traverse_config(c, false);

@@ -303,14 +303,15 @@ __global__ __launch_bounds__(SBLOCK) PT_SHADE_ATTR void k_shade(DevScene sc, Dev
         bool alive = false, shadow = false, skipped = false, emitted = false;
         bool neg_x = false, neg_y = false, neg_z = false;          // ray_sort: octant of the new direction
         if (i < count) {
-            const uint32_t p = queue ? queue[i] : i;
+            const uint32_t q = queue ? queue[i] : i;                         // where this ray's state is
             const float2 h2 = ld_stream(&hits[i]);
             if (!(h2.x < 0.0f)) {                                            // pt.wgsl:646: miss adds zero
-                const float4 o4 = ld_stream(&P.O[p]), d4 = ld_stream(&P.D[p]);
+                const float4 o4 = ld_stream(&P.O[q]), d4 = ld_stream(&P.D[q]);
+                const uint32_t p = sp.pid_in ? sp.pid_in[q] : q;             // the path (its radiance); q itself while the state is in place
                 uint32_t rng = __float_as_uint(o4.w);
                 const v3 ro = xyz(o4), rd = xyz(d4);
                 v3 thr = mk3(1.0f, 1.0f, 1.0f);                                      // pt.wgsl:639; raygen stores no throughput
-                if (sp.bounce != 0u) { const float2 c2 = ld_stream(&P.C[p]); thr = mk3(d4.w, c2.x, c2.y); }
+                if (sp.bounce != 0u) { const float2 c2 = ld_stream(&P.C[q]); thr = mk3(d4.w, c2.x, c2.y); }
                 const HitInfo hit = make_hitinfo(sc, ro, rd, h2.x, __float_as_uint(h2.y));
                 if (hit.emission.x > 0.0f || hit.emission.y > 0.0f || hit.emission.z > 0.0f) {   // pt.wgsl:652-658
                     float att = rcp1(1.0f + hit.t * hit.t);
@@ -365,9 +366,16 @@ __global__ __launch_bounds__(SBLOCK) PT_SHADE_ATTR void k_shade(DevScene sc, Dev
                         }
                         if (alive && sp.bounce + 1u < sp.max_bounces) {
                             neg_x = nd.x < 0.0f; neg_y = nd.y < 0.0f; neg_z = nd.z < 0.0f;
-                            st_stream(&P.O[p], make_float4(no.x, no.y, no.z, __uint_as_float(rng)));
-                            st_stream(&P.D[p], make_float4(nd.x, nd.y, nd.z, thr.x));
-                            st_stream(&P.C[p], make_float2(thr.y, thr.z));
+                            if (sp.O_out) {                                   // the state follows the queue (pt_device.h ShadeParams)
+                                st_stream(&sp.O_out[i], make_float4(no.x, no.y, no.z, __uint_as_float(rng)));
+                                st_stream(&sp.D_out[i], make_float4(nd.x, nd.y, nd.z, thr.x));
+                                st_stream(&sp.C_out[i], make_float2(thr.y, thr.z));
+                                if (sp.pid_out) sp.pid_out[i] = p;
+                            } else {
+                                st_stream(&P.O[q], make_float4(no.x, no.y, no.z, __uint_as_float(rng)));
+                                st_stream(&P.D[q], make_float4(nd.x, nd.y, nd.z, thr.x));
+                                st_stream(&P.C[q], make_float2(thr.y, thr.z));
+                            }
                         }
                     }
                 }

@@ -109,15 +109,6 @@ __device__ unsigned long long g_util[2][16];
 
 struct GlobalMem {
     glb_f4p wn, tp;
-    struct RayK {};
-    PT_DEV static bool in_range(v3, v3) { return true; }
-    PT_DEV void prep(v3, v3, RayK &) const {}
-    PT_DEV void test(uint32_t i, v3 o, v3 inv, const RayK &, bool &hl, bool &hr, float &tl, float &tr, uint32_t &lref, uint32_t &rref) const {
-        Boxes nb; node(i, false, nb);
-        hl = slab(nb.lx0, nb.ly0, nb.lz0, nb.lx1, nb.ly1, nb.lz1, o, inv, tl);
-        hr = slab(nb.rx0, nb.ry0, nb.rz0, nb.rx1, nb.ry1, nb.rz1, o, inv, tr);
-        lref = nb.lref; rref = nb.rref;
-    }
     PT_DEV void node(uint32_t i, bool, Boxes &o) const { float4 a, b, c, r; load_node(wn + 4u * (size_t)i, a, b, c, r); boxes_of(a, b, c, r, o); }
     PT_DEV bool open(uint32_t ref, bool, v3, v3, float, uint32_t &first, uint32_t &cnt, uint32_t &cursor) const {
         open_plain(ref, first, cnt, cursor); return true;
@@ -132,15 +123,6 @@ struct GlobalMem {
 template <bool TRIS_IN_LDS>
 struct LdsMem {
     lds_f4p wn, tl; glb_f4p tg;
-    struct RayK {};
-    PT_DEV static bool in_range(v3, v3) { return true; }
-    PT_DEV void prep(v3, v3, RayK &) const {}
-    PT_DEV void test(uint32_t i, v3 o, v3 inv, const RayK &, bool &hl, bool &hr, float &tl, float &tr, uint32_t &lref, uint32_t &rref) const {
-        Boxes nb; node(i, false, nb);
-        hl = slab(nb.lx0, nb.ly0, nb.lz0, nb.lx1, nb.ly1, nb.lz1, o, inv, tl);
-        hr = slab(nb.rx0, nb.ry0, nb.rz0, nb.rx1, nb.ry1, nb.rz1, o, inv, tr);
-        lref = nb.lref; rref = nb.rref;
-    }
     PT_DEV void node(uint32_t i, bool, Boxes &o) const {
         lds_f4p p = wn + 4u * i;
         boxes_of(as_f4(p[0]), as_f4(p[1]), as_f4(p[2]), as_f4(p[3]), o);
@@ -180,15 +162,6 @@ struct QuantMem {
     glb_u4p qn; glb_u32p ls; glb_f4p tp;
     float ox, oy, oz, sx, sy, sz;
     lds_u4p qc; uint32_t n_cached;        // the first n_cached nodes (the top levels, numbered breadth-first) also live in LDS
-    struct RayK {};
-    PT_DEV static bool in_range(v3, v3) { return true; }
-    PT_DEV void prep(v3, v3, RayK &) const {}
-    PT_DEV void test(uint32_t i, v3 o, v3 inv, const RayK &, bool &hl, bool &hr, float &tl, float &tr, uint32_t &lref, uint32_t &rref) const {
-        Boxes nb; node(i, false, nb);
-        hl = slab(nb.lx0, nb.ly0, nb.lz0, nb.lx1, nb.ly1, nb.lz1, o, inv, tl);
-        hr = slab(nb.rx0, nb.ry0, nb.rz0, nb.rx1, nb.ry1, nb.rz1, o, inv, tr);
-        lref = nb.lref; rref = nb.rref;
-    }
     PT_DEV void node(uint32_t i, bool, Boxes &b) const {
         u4v l, r;
         if (i < n_cached) { l = qc[2u * i]; r = qc[2u * i + 1u]; }
@@ -337,7 +310,6 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
     uint32_t spn = 0;                       // SPILL: entries of this lane in the spill area
     v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), inv = mk3(0, 0, 0);
     float tlim = 0.0f, limit = __builtin_inff();
-    typename Mem::RayK rk{};
     Hit best; best.t = __builtin_inff(); best.tri = PT_REF_NONE;
 #ifdef PT_UTIL_STATS
     uint32_t ut[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -358,14 +330,13 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                 sp = bot; lp = top; spn = 0u; cur = PT_REF_NONE;
                 limit = (ANY && CULL) ? cull_limit(tlim) : __builtin_inff();      // NaN for a directional light: never culls
                 const bool regular = __builtin_isfinite(inv.x) & __builtin_isfinite(inv.y) & __builtin_isfinite(inv.z) &
-                                     (inv.x != 0.0f) & (inv.y != 0.0f) & (inv.z != 0.0f) & Mem::in_range(o, inv);
+                                     (inv.x != 0.0f) & (inv.y != 0.0f) & (inv.z != 0.0f);
                 // bounded: the triangle test's determinant stays below 2^100 for this ray (NaN compares false): pt_math.h tri_test_t.
                 // ONE flag for both kinds of special ray (a second wave-wide mask would take the kernel's scalar registers past 80
                 // and with them the second workgroup per CU): they run the careful copy of the streams below, and where the
                 // hierarchy was rebuilt they walk the tree as uploaded.
                 const bool bounded = (__builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z)) <= sc.tri_safe_dsum;
                 slow = !(regular & bounded);
-                m.prep(o, inv, rk);
                 float tm;
                 if (want && sc.root_ref != PT_REF_NONE &&
                     slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2],
@@ -443,18 +414,17 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                         sp = bot;
                     }
                     float tl, tr;
-                    bool hl, hr;
-                    uint32_t lref, rref;
+                    Boxes nb;
                     if (REF && has_fast && slow) {
                         float4 a, b, c, r;
                         load_node((glb_f4p)sc.ref_wnodes + 4u * (size_t)cur, a, b, c, r);
-                        Boxes nb; boxes_of(a, b, c, r, nb);
-                        hl = slab(nb.lx0, nb.ly0, nb.lz0, nb.lx1, nb.ly1, nb.lz1, o, inv, tl);
-                        hr = slab(nb.rx0, nb.ry0, nb.rz0, nb.rx1, nb.ry1, nb.rz1, o, inv, tr);
-                        lref = nb.lref; rref = nb.rref;
+                        boxes_of(a, b, c, r, nb);
                     } else {
-                        m.test(cur, o, inv, rk, hl, hr, tl, tr, lref, rref);
+                        m.node(cur, false, nb);
                     }
+                    bool hl = slab(nb.lx0, nb.ly0, nb.lz0, nb.lx1, nb.ly1, nb.lz1, o, inv, tl);
+                    bool hr = slab(nb.rx0, nb.ry0, nb.rz0, nb.rx1, nb.ry1, nb.rz1, o, inv, tr);
+                    const uint32_t lref = nb.lref, rref = nb.rref;
                     if (CULL) { hl = hl & !(tl > limit); hr = hr & !(tr > limit); }
                     const bool ll = (lref & PT_REF_LEAF) != 0u, rl = (rref & PT_REF_LEAF) != 0u;
                     if (hl & ll) { *lp = lref; lp -= stride; }

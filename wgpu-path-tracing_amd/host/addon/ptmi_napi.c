@@ -167,6 +167,7 @@ static void read_options(napi_env env, napi_value obj, ptmi_options *o) {
     o->overlap = get_u32_prop(env, obj, "overlap", o->overlap);
     o->worklist = get_u32_prop(env, obj, "worklist", o->worklist);
     o->tails = get_u32_prop(env, obj, "tails", o->tails);
+    o->state = get_u32_prop(env, obj, "state", o->state);
 }
 
 static napi_value js_set_options(napi_env env, napi_callback_info info) {
@@ -287,6 +288,7 @@ static napi_value stats_object(napi_env env, const ptmi_stats *s) {
     set_num(env, o, "shadowTraced", (double)s->shadow_traced); set_num(env, o, "uploadMs", s->upload_ms);
     set_num(env, o, "bvhDepth", s->bvh_depth); set_num(env, o, "traversalUsed", s->traversal_used);
     set_num(env, o, "framesPerBatchUsed", s->frames_per_batch_used);
+    set_num(env, o, "worklistUsed", s->worklist_used); set_num(env, o, "stateUsed", s->state_used);
     return o;
 }
 

@@ -29,11 +29,18 @@ export interface TraceOptions {
   /** 0 / 1 / 2 (library default): group each 1024-slot window of the ray queue by direction octant */
   raySort?: 0 | 1 | 2;
   /** 0 / 1 / 2 (library default): run the shadow kernel on a second stream beside the next bounce */
-  overlap?: 0 | 1 | 2;
+  overlap?: 0 | 1 | 2 | 3;
+  /** 0 (library default) / 1 off / 2 on: triangle tests of the LDS traversal kernels through a per-wave work list */
+  worklist?: 0 | 1 | 2;
+  /** 0 (library default) / 1 every kernel its own launch / 2 shadow(b) and extend(b + 1) in one traversal launch */
+  tails?: 0 | 1 | 2;
+  /** 0 (library default) / 1 ray state in place by path id / 2 the state follows the queue (denser gathers in late bounces) */
+  state?: 0 | 1 | 2;
 }
 export interface Stats {
   paths: number; segments: number; shadowRays: number; frames: number; dispatches: number;
   gpuMs: number; extendMs: number; shadeMs: number; shadowMs: number; bvhDepth: number; traversalUsed: number;
+  shadowTraced: number; uploadMs: number; framesPerBatchUsed: number; worklistUsed: number; stateUsed: number;
 }
 export class Renderer {
   constructor(options?: { device?: number; width?: number; height?: number; options?: TraceOptions });
