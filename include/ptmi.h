@@ -88,8 +88,11 @@ typedef struct ptmi_options {
                                    of the leaves they open as (ray lane, triangle) items in LDS and all 64 lanes take one item each,
                                    the closest hit reduced with an LDS 64-bit minimum on (t bits, triangle) — the same (t, lowest
                                    index) rule, so results are unchanged. 0 = library default, 1 = off, 2 = on where it fits */
-    uint32_t tails;             /* how the last bounces' small queues are traced: 0 = library default, 1 = every kernel its own launch,
-                                   2 = `shadow` of bounce b and `extend` of bounce b + 1 share ONE traversal launch (results unchanged) */
+    uint32_t tails;             /* how the last bounces' small queues (from bounce 4 on, a tenth of the rays) are scheduled when `shadow` has
+                                   its own stream: 0 = library default, 1 = like every other bounce (shadow(b) beside extend / shade of
+                                   bounce b + 1), 2 = on ONE stream, every kernel by itself, shadow(b) behind the compaction of bounce b
+                                   (no second persistent traversal grid holding the CUs' LDS while the next small extend arrives).
+                                   Results unchanged: `shadow` stays the only kernel adding to the radiance, in bounce order */
     uint32_t state;             /* where a path's ray state (origin + RNG, direction, throughput) lives between bounces: 1 = in place,
                                    indexed by path id for the whole batch (by bounce 4 the survivors are 7 % of the paths: every read
                                    fetches a memory sector for 16 bytes of it); 2 = it follows the queue: `shade` of bounce b writes the
@@ -127,7 +130,7 @@ typedef struct ptmi_stats {
     /* ABI 3 */
     uint32_t worklist_used;     /* of the last dispatch / per-stage call: bit 0 the closest-hit kernel, bit 1 the any-hit kernel ran the
                                    per-wave work list (ptmi_options.worklist) */
-    uint32_t tails_used;        /* ... 1: shadow(b) and extend(b + 1) shared one traversal launch (ptmi_options.tails) */
+    uint32_t tails_used;        /* ... 1: the last bounces ran on one stream (ptmi_options.tails = 2) */
     uint32_t state_used;        /* ... 1: ray state in place by path id, 2: it followed the queue (ptmi_options.state) */
     uint32_t reserved_stats;
 } ptmi_stats;

@@ -601,7 +601,12 @@ static v3 trace(const pto_scene *s, uint32_t *rng, ray_t ray, uint32_t max_bounc
             L[6] = thr.x; L[7] = thr.y; L[8] = thr.z; L[9] = res.x; L[10] = res.y; L[11] = res.z;
             memcpy(&L[12], rng, 4); L[13] = raw.t; memcpy(&L[14], &raw.tri, 4); L[15] = 1.0f;
         }
-        if (hit.t < 0.0f) break;                                             /* :646-649 (adds zero) */
+        if (hit.t < 0.0f) {                                                  /* :646-649 */
+            /* `result += throughput * vec3f(0.0)`: nothing for a finite throughput, NaN in every component whose
+             * throughput is infinite or NaN (found by oracle/pt_literal.c, round 3; the kernels follow: shade.hip) */
+            res = add3(res, mul3(thr, V3(0.0f, 0.0f, 0.0f)));
+            break;
+        }
         c->closest_hits++;
         if (hit.emission.x > 0.0f || hit.emission.y > 0.0f || hit.emission.z > 0.0f) {  /* :652 */
             float att = 1.0f / (1.0f + hit.t * hit.t);

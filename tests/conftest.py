@@ -14,7 +14,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # native libraries are built in-tree by __graft_entry__.build(); build lazily if a test run starts without them
     need = [os.path.join(PKG, "lib", "libptmi_scene.so"), os.path.join(ROOT, "oracle", "build", "libpt_oracle.so"),
-            os.path.join(ROOT, "oracle", "build", "libpt_oracle_strict.so")]
+            os.path.join(ROOT, "oracle", "build", "libpt_oracle_strict.so"), os.path.join(ROOT, "oracle", "build", "libpt_literal.so")]
     if not all(os.path.exists(p) for p in need):
         import subprocess
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
@@ -41,6 +41,13 @@ def oracle():
 def oracle_strict():
     from oracle_lib import Oracle
     return Oracle(strict=True)
+
+
+@pytest.fixture(scope="session")
+def oracle_literal():
+    """oracle/pt_literal.c: the reference's shader restated in its own shape, sharing no code with pt_oracle.c"""
+    from oracle_lib import Oracle
+    return Oracle(literal=True)
 
 
 @pytest.fixture(scope="session")

@@ -41,8 +41,10 @@ def _ptr(a):
 
 
 class Oracle:
-    def __init__(self, strict=False):
-        name = "libpt_oracle_strict.so" if strict else "libpt_oracle.so"
+    def __init__(self, strict=False, literal=False):
+        """strict: pt_oracle.c built with literal arithmetic; literal: oracle/pt_literal.c, the independent transcription in the
+        reference's own shape (it offers the subset of entry points the literal comparisons use)"""
+        name = "libpt_literal.so" if literal else "libpt_oracle_strict.so" if strict else "libpt_oracle.so"
         path = os.path.join(ORACLE_DIR, "build", name)
         if not os.path.exists(path):
             subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
@@ -60,7 +62,8 @@ class Oracle:
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         self.L = L
         self.strict = bool(L.pto_is_strict())
-        assert self.strict == strict
+        self.literal = L.pto_is_strict() == 2
+        assert self.literal == literal and self.strict == (strict or literal)
 
     # -- scene marshalling ---------------------------------------------------
     @staticmethod

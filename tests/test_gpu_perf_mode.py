@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("name", ["cornell", "feature_box"])
-def test_perf_mode_is_statistically_the_same_image(gpu_ctx, oracle, oracle_strict, name):
+def test_perf_mode_is_statistically_the_same_image(gpu_ctx, oracle, oracle_literal, name):
     sc = scenes.make(name)
     W = H = 256
     frames = 64
@@ -33,7 +33,7 @@ def test_perf_mode_is_statistically_the_same_image(gpu_ctx, oracle, oracle_stric
     assert np.array_equal(exact.view(np.uint32), ref.view(np.uint32))           # parity mode is untouched by the second build
     assert st1.paths == st0.paths and abs(st1.segments / st0.segments - 1) < 1e-3 and abs(st1.shadow_rays / st0.shadow_rays - 1) < 1e-3
     assert np.isfinite(fast[..., :3]).all() == np.isfinite(exact[..., :3]).all()
-    lit, _, sigma = literal_statistics(oracle_strict, sc, W, H, frames, 8, 1)
+    lit, _, sigma = literal_statistics(oracle_literal, sc, W, H, frames, 8, 1)
     w0, m0 = compare(fast, ref, sigma, max_sigmas=3.0, max_mean_rel=5e-3)       # against the contract oracle (= parity mode)
     w1, m1 = compare(fast, lit, sigma, max_sigmas=3.0, max_mean_rel=5e-3)       # against the literal oracle
     print(f"perf mode {name}: vs contract worst tile {w0:.2f} sigma, mean {m0:+.2e}; vs literal {w1:.2f} sigma, mean {m1:+.2e}")

@@ -87,3 +87,26 @@ def test_state_follows_the_queue_random_scene_fuzz(st_ctx, oracle, seed):
         assert st.state_used == 2
         assert (st.segments, st.shadow_rays, st.paths) == (ost.segments, ost.shadow_rays, ost.paths)
         assert_same_floats(got, ref, f"radiance (seed {seed}, keep {keep})")
+
+
+@pytest.mark.parametrize("name,bounces", [("cornell", 8), ("cornell", 5), ("cornell", 4), ("feature_box", 8)])
+def test_serial_tail_is_invisible(st_ctx, oracle, scene_factory, name, bounces):
+    """ptmi_options.tails = 2: from bounce 4 on `shadow` runs on the main stream behind its bounce's compaction instead of on
+    the side stream beside the next bounce. The radiance is still added by that one kernel in bounce order: same bits, for
+    both state modes, several batches, and bounce counts around the switch."""
+    sc = scene_factory(name)
+    W, H, frames = 96, 64, 5
+    cam = layout.make_camera(W, H, aperture=0.001, focus_distance=5.0)
+    ref, ost = oracle.render(sc, cam, frames, max_bounces=bounces, do_mis=1)
+    st_ctx.upload_scene(sc)
+    st_ctx.resize(W, H)
+    for state, fpb in ((1, 0), (2, 2)):
+        st_ctx.set_options(state=state, tails=2, overlap=1, max_bounces=bounces, do_mis=1, frames_per_batch=fpb)
+        st_ctx.reset_stats()
+        st_ctx.dispatch(cam, frames)
+        got = st_ctx.read_output()
+        st = st_ctx.stats()
+        assert st.tails_used == (1 if bounces > 4 else 0)
+        assert (st.segments, st.shadow_rays, st.paths) == (ost.segments, ost.shadow_rays, ost.paths)
+        assert_same_floats(got, ref, f"radiance ({name}, {bounces} bounces, state {state})")
+    st_ctx.set_options(tails=0)

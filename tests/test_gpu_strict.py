@@ -1,5 +1,7 @@
-"""The HIP path against the LITERAL oracle build (PT_STRICT: IEEE '/', no FMA, libm sin/cos — a transcription of
-src/shader/pt.wgsl:638-762 with none of the arithmetic contract's choices), directly, at BASELINE configs[0]'s size.
+"""The HIP path against the LITERAL oracle (oracle/pt_literal.c: the reference's shader restated in its own shape — a whole
+HitInfo per accepted candidate, sampleLight tracing its own shadow ray, private RNG state, IEEE '/', no FMA, libm sin/cos/pow —
+sharing no code with pt_oracle.c, and bit-identical to that file's PT_STRICT build:
+tests/test_oracle.py::test_literal_transcription_equals_the_strict_build), directly, at BASELINE configs[0]'s size.
 
 Every other GPU test compares the HIP path bit for bit with the oracle's *contract* build — two implementations of
 one arithmetic specification. This file is the bridge to the transcription that shares nothing with the kernels but
@@ -41,14 +43,14 @@ def _tile_means(img):
     return img[..., :3].reshape(h // TILE, TILE, w // TILE, TILE, 3).mean(axis=(1, 3))
 
 
-def literal_statistics(oracle_strict, sc, W, H, frames, bounces, mis, cam_kw=None):
+def literal_statistics(oracle_literal, sc, W, H, frames, bounces, mis, cam_kw=None):
     """The literal build's accumulated image, and the standard error of each tile's mean from its per-frame samples."""
     cam_kw = cam_kw or {}
-    ref, st = oracle_strict.render(sc, layout.make_camera(W, H, **cam_kw), frames, max_bounces=bounces, do_mis=mis)
+    ref, st = oracle_literal.render(sc, layout.make_camera(W, H, **cam_kw), frames, max_bounces=bounces, do_mis=mis)
     per = []
     for k in range(frames):
         out = np.zeros((H, W, 4), np.float32)       # a lone frame k > 0 leaves mix(0, c, 1/(k+1)) = c/(k+1) (pt.wgsl:757)
-        oracle_strict.render(sc, layout.make_camera(W, H, frame_index=k, **cam_kw), 1, max_bounces=bounces, do_mis=mis, out=out)
+        oracle_literal.render(sc, layout.make_camera(W, H, frame_index=k, **cam_kw), 1, max_bounces=bounces, do_mis=mis, out=out)
         per.append(_tile_means(out * np.float32(k + 1 if k else 1)))
     per = np.stack(per)
     assert np.abs(per.mean(0) - _tile_means(ref)).max() < 1e-5          # the per-frame samples are the image's samples
@@ -67,7 +69,7 @@ def compare(got, ref, sigma, max_sigmas, max_mean_rel):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(NODE is None, reason="node is not installed")
-def test_config0_literally_through_node_against_the_literal_oracle(tmp_path, oracle_strict):
+def test_config0_literally_through_node_against_the_literal_oracle(tmp_path, oracle_literal):
     """BASELINE configs[0] as written: the Cornell box as a .glb, 256x256, frames 0..15, 4 bounces, MIS off, through
     Node -> N-API addon -> C ABI -> HIP; checked against the literal oracle on the blobs the JS host built."""
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "wgpu-path-tracing_amd"), "all"], stdout=subprocess.DEVNULL)
@@ -85,7 +87,7 @@ def test_config0_literally_through_node_against_the_literal_oracle(tmp_path, ora
                                   text=True)
     st = json.loads(out.strip().splitlines()[-1])
     got = np.fromfile(tmp_path / "o.f32", np.float32).reshape(H, W, 4)
-    ref, ost, sigma = literal_statistics(oracle_strict, sc, W, H, 16, 4, 0)
+    ref, ost, sigma = literal_statistics(oracle_literal, sc, W, H, 16, 4, 0)
     assert st["paths"] == ost.paths == W * H * 16
     assert abs(st["segments"] / ost.segments - 1) < 1e-3            # a handful of paths end a bounce earlier or later
     worst, mean_rel = compare(got, ref, sigma, max_sigmas=3.0, max_mean_rel=2e-3)
@@ -93,7 +95,7 @@ def test_config0_literally_through_node_against_the_literal_oracle(tmp_path, ora
 
 
 @pytest.mark.gpu
-def test_mis_on_256x256x64_against_the_literal_oracle(gpu_ctx, oracle_strict):
+def test_mis_on_256x256x64_against_the_literal_oracle(gpu_ctx, oracle_literal):
     """The MIS-on path (next-event records, shadow kernel) at 256x256, 64 frames, 8 bounces, through the C ABI."""
     sc = scenes.make("cornell")
     W = H = 256
@@ -104,7 +106,7 @@ def test_mis_on_256x256x64_against_the_literal_oracle(gpu_ctx, oracle_strict):
     gpu_ctx.dispatch(layout.make_camera(W, H), 64)
     got = gpu_ctx.read_output()
     st = gpu_ctx.stats()
-    ref, ost, sigma = literal_statistics(oracle_strict, sc, W, H, 64, 8, 1)
+    ref, ost, sigma = literal_statistics(oracle_literal, sc, W, H, 64, 8, 1)
     assert st.paths == ost.paths and abs(st.segments / ost.segments - 1) < 1e-3
     assert abs(st.shadow_rays / ost.shadow_rays - 1) < 1e-3
     # 5e-3: the systematic +0.33 % of the module docstring (light samples on the knife edge of pt.wgsl:465)
@@ -113,7 +115,7 @@ def test_mis_on_256x256x64_against_the_literal_oracle(gpu_ctx, oracle_strict):
 
 
 @pytest.mark.gpu
-def test_first_hits_match_the_literal_oracle(gpu_ctx, oracle_strict):
+def test_first_hits_match_the_literal_oracle(gpu_ctx, oracle_literal):
     """raygen -> extend on the device against the literal raygen -> traversal: the same triangle on >= 99.9 % of the
     camera rays of a 256x256 frame (the rest graze an edge shared by two triangles), t within a few ulp where equal."""
     sc = scenes.make("cornell")
@@ -124,10 +126,10 @@ def test_first_hits_match_the_literal_oracle(gpu_ctx, oracle_strict):
     fr = np.zeros(W * H, np.uint32)
     gpu_ctx.upload_scene(sc)
     o, d, rng = gpu_ctx.debug_raygen(cam, xs, ys, fr)
-    ob, db, rb = oracle_strict.raygen(cam, xs, ys, fr)
+    ob, db, rb = oracle_literal.raygen(cam, xs, ys, fr)
     assert np.array_equal(rng, rb) and np.abs(d - db).max() < 1e-6 and np.abs(o - ob).max() < 1e-6
     t, tri, _, _ = gpu_ctx.debug_intersect(o, d)
-    tb, trib, _, _, _ = oracle_strict.intersect(sc, ob, db)
+    tb, trib, _, _, _ = oracle_literal.intersect(sc, ob, db)
     same = tri == trib.astype(np.uint32)
     assert same.mean() >= 0.999, same.mean()
     hit = same & (tb > 0)

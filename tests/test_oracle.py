@@ -295,3 +295,35 @@ def test_trace_path_log(oracle):
     assert 2 <= len(log) <= 9 and log[-1][15] == 0.0 and (log[:-1, 15] == 1.0).all()
     out, _ = oracle.render(sc, cam, 1)
     assert np.array_equal(np.minimum(rad, np.float32(2.5)), out[10, 16, :3])
+
+
+@pytest.mark.parametrize("name,mis,bounces,ap", [("cornell", 1, 8, 0.001), ("cornell", 0, 4, 0.0), ("cornell_glass", 1, 8, 0.0),
+                                                 ("feature_box", 1, 8, 0.05), ("cornell_spheres", 1, 8, 0.001),
+                                                 ("random_soup", 1, 8, 0.02)])
+def test_literal_transcription_equals_the_strict_build(oracle_strict, oracle_literal, scene_factory, name, mis, bounces, ap):
+    """Two literal restatements of pt.wgsl that share no code — pt_oracle.c's PT_STRICT build (the contract build's control flow
+    with literal arithmetic: the shading state rebuilt once for the winning triangle, RNG by pointer, guarded 1024-entry stack)
+    and oracle/pt_literal.c (the reference's own shape: a whole HitInfo per accepted candidate, sampleLight tracing its own
+    shadow ray, private RNG state, 64-entry stack) — must agree on EVERY bit: radiance, counters, camera rays, RNG states,
+    closest hits and shadow predicates. A mis-reading of the WGSL would have to be made twice, in two different structures."""
+    assert oracle_literal.literal and oracle_strict.strict and not oracle_strict.literal
+    sc = scene_factory(name) if name != "random_soup" else __import__("ptmi.scenes", fromlist=["x"]).random_soup(7)
+    W, H, frames = 56, 40, 3
+    cam = layout.make_camera(W, H, aperture=ap, focus_distance=2.8)
+    a, sa = oracle_strict.render(sc, cam, frames, max_bounces=bounces, do_mis=mis)
+    b, sb = oracle_literal.render(sc, cam, frames, max_bounces=bounces, do_mis=mis)
+    assert (sa.segments, sa.shadow_rays, sa.paths, sa.closest_hits, sa.nodes_visited, sa.tris_tested) == \
+           (sb.segments, sb.shadow_rays, sb.paths, sb.closest_hits, sb.nodes_visited, sb.tris_tested)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{(a.view(np.uint32) != b.view(np.uint32)).sum()} radiance words differ"
+    ys, xs = np.mgrid[0:H, 0:W]
+    fr = (np.arange(W * H) % 5).astype(np.uint32)
+    oa, da, ra = oracle_strict.raygen(cam, xs.ravel(), ys.ravel(), fr)
+    ob, db, rb = oracle_literal.raygen(cam, xs.ravel(), ys.ravel(), fr)
+    assert np.array_equal(ra, rb) and np.array_equal(oa.view(np.uint32), ob.view(np.uint32)) and np.array_equal(da.view(np.uint32), db.view(np.uint32))
+    ta, tria, ua, va, _ = oracle_strict.intersect(sc, oa, da)
+    tb, trib, ub, vb, _ = oracle_literal.intersect(sc, oa, da)
+    assert np.array_equal(tria, trib)
+    for x, y in ((ta, tb), (ua, ub), (va, vb)):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    dist = np.where(ta > 0, ta + np.float32(1e-6) * (np.arange(len(ta)) % 5), np.float32(-1.0)).astype(np.float32)
+    assert np.array_equal(oracle_strict.occluded(sc, oa, da, dist), oracle_literal.occluded(sc, oa, da, dist))

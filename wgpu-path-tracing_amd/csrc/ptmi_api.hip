@@ -700,6 +700,10 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     // 10 - 12 % SLOWER on every config (profiles/README.md): two persistent traversal grids, each sized to own every CU's LDS,
     // take turns instead of sharing.
     const bool side = nee && c->opt.overlap != 0;
+    // tails = 2 (an experiment, measured in profiles/README.md): from bounce kTailBounce on — after the Russian roulette of pt.wgsl:699-705
+    // has thinned the queues to a tenth — `shadow` runs on the main stream behind its bounce's compaction instead of beside the next bounce
+    constexpr uint32_t kTailBounce = 4;
+    const bool serial_tail = c->opt.tails == 2 && c->opt.overlap != 3 && c->opt.max_bounces > kTailBounce;
     bool two_lanes = c->opt.overlap == 3 && F >= 2;
     uint32_t Fsub = two_lanes ? (F + 1) / 2 : F;                    // frames per traced batch
     if (npix * Fsub > 0xFFFFFF00ull) return fail(c, PTMI_E_UNSUPPORTED, "batch of %llu paths exceeds 2^32", (unsigned long long)(npix * Fsub));
@@ -730,6 +734,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     c->st.frames_per_batch_used = Fsub;
     c->st.worklist_used = (cfg0.worklist ? 1u : 0u) | ((nee && cfg_shadow0.worklist) ? 2u : 0u);
     c->st.state_used = state2 ? 2u : 1u;
+    c->st.tails_used = (side && serial_tail) ? 1u : 0u;
     c->st.radiance_stride_bytes = 4u * (PT_L_STRIDE ? (uint32_t)PT_L_STRIDE : ((cfg0.quantized || cfg_shadow0.quantized) ? 4u : 3u));
     const int blocks = c->n_cu * 8;
 #ifndef PT_SHADE_WGS_PER_CU
@@ -794,7 +799,15 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
                                     ln.word_off, ln.queue[cur ^ 1], &ln.counts[b + 1], ln.sq[par], &ln.counts[kShadowCount + par],
                                     c->d_stats, b, last ? 0 : 1, octm, (uint32_t)ln.mask_words); }
                 if (two_lanes && b == mid_bounce) { HIP_TRY(c, hipEventRecord(ln.ev_mid, ms)); ln.mid_recorded = true; }
-                if (side) {
+                if (side && serial_tail && b >= kTailBounce) {
+                    // tails = 2: the small queues of the last bounces on ONE stream, every kernel by itself. `shadow` stays the only
+                    // kernel that adds to L and keeps its bounce order: the first one here waits for the side stream's last one.
+                    if (b == kTailBounce) HIP_TRY(c, hipStreamWaitEvent(ms, ln.ev_shadow[(b - 1u) & 1u], 0));
+                    { Timed t(c, 3, t3, ms);
+                      pt_launch_shadow(ms, blocks, cfg_shadow, c->sc, ln.paths, ln.sh[par], ln.sq[par],
+                                       &ln.counts[kShadowCount + par], nullptr); }
+                    HIP_TRY(c, hipEventRecord(ln.ev_shadow[par], ms));
+                } else if (side) {
                     HIP_TRY(c, hipEventRecord(ln.ev_ready, ms));
                     HIP_TRY(c, hipStreamWaitEvent(ss, ln.ev_ready, 0));
                     { Timed t(c, 3, t3, ss);

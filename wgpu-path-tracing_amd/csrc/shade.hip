@@ -379,6 +379,25 @@ __global__ __launch_bounds__(SBLOCK) PT_SHADE_ATTR void k_shade(DevScene sc, Dev
                         }
                     }
                 }
+            } else if (sp.bounce != 0u) {
+                // pt.wgsl:646-648: a miss adds `throughput * vec3f(0.0)` — nothing while the throughput is finite (x + +-0 = x, and
+                // the radiance is never -0), NaN in every component whose throughput is infinite or NaN (degenerate materials
+                // only; the camera ray's throughput is 1). Such a path leaves a record like an emissive hit's.
+                const float tx = reinterpret_cast<const float *>(&P.D[q])[3];
+                const float2 c2 = ld_stream(&P.C[q]);
+                if (!(__builtin_isfinite(tx) & __builtin_isfinite(c2.x) & __builtin_isfinite(c2.y))) {
+                    const uint32_t p = sp.pid_in ? sp.pid_in[q] : q;
+                    const v3 e = mk3(tx * 0.0f, c2.x * 0.0f, c2.y * 0.0f);
+                    if (sp.emit_records) {
+                        st_stream(&S.SO[i], make_float4(0.0f, 0.0f, 0.0f, -2.0f));
+                        st_stream(&S.SD[i], make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(p)));
+                        S.SC[i] = rgb_sc{e.x, e.y, e.z};
+                        shadow = true; emitted = true;
+                    } else {
+                        const rgb_sc l = P.ldL(p);
+                        P.stL(p, l.x + e.x, l.y + e.y, l.z + e.z);
+                    }
+                }
             }
         }
         const uint64_t am = __ballot(alive), sm = __ballot(shadow), zm = __ballot(skipped), em = __ballot(emitted);
