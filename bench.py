@@ -57,7 +57,7 @@ def shadow_bytes_per_ray(l_bytes=12):
     per-path radiance at 16-byte stride (scenes walked from memory; ptmi_stats.radiance_stride_bytes)."""
     return 4 + SHADOW_RECORD_BYTES + 2 * l_bytes
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
-PROFILE_TAG = "r02"                     # profiles/<tag>_cfgN_*.json are the counter passes replayed in `roofline`
+PROFILE_TAG = "r03"                     # profiles/<tag>_cfgN_*.json are the counter passes replayed in `roofline`
 
 CONFIGS = {
     0: dict(scene="cornell", width=256, height=256, spp=16, fps=16, bounces=4, mis=0, aperture=0.001, focus=5.0,
