@@ -1,10 +1,10 @@
 #!/bin/bash
-# Copies what tools/sessions/session15.sh left under gpurun_out/ into profiles/ (the tracked evidence of a round).
+# Copies what the evidence session (tools/sessions/r03/s12.sh; round 2: tools/sessions/session15.sh) left under gpurun_out/ into profiles/ (the tracked evidence of a round).
 # usage: tools/collect_profiles.sh r02
 tag=${1:-r02}; cd "$(dirname "$0")/.."
 for f in gpurun_out/prof_$tag/${tag}_cfg*_{bench,bench_profiled,pmc,counters,per_bounce,lane_stats}.json gpurun_out/prof_$tag/${tag}_cfg1_bench_one_stream.json \
          gpurun_out/prof_$tag/${tag}_cfg*_kernel_stats.csv; do [ -s "$f" ] && cp "$f" profiles/; done
-[ -s gpurun_out/s15/upload.log ] && cp gpurun_out/s15/upload.log profiles/${tag}_upload_times.txt
+[ -s gpurun_out/s12/upload.log ] && cp gpurun_out/s12/upload.log profiles/${tag}_upload_times.txt
 python3 - "$tag" <<'PY'
 import json, sys, glob
 tag = sys.argv[1]

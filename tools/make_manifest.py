@@ -14,7 +14,7 @@ import bench  # noqa: E402
 tag, commit = sys.argv[1], sys.argv[2]
 files = {}
 for f in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
-    if f.startswith(tag + "_") and not f.endswith("_manifest.json"):
+    if f.startswith(tag + "_") and not f.endswith("_manifest.json") and os.path.isfile(os.path.join(ROOT, "profiles", f)):
         files[f] = hashlib.sha256(open(os.path.join(ROOT, "profiles", f), "rb").read()).hexdigest()[:16]
 out = {"tag": tag, "commit": commit, "csrc_sha": bench.csrc_sha(), "files": files,
        "note": "csrc_sha = sha256 over wgpu-path-tracing_amd/csrc/*.{hip,h} and include/*.h (names + contents), first 16 hex digits"}

@@ -57,6 +57,12 @@ constexpr int REFILL_AT = PT_REFILL_AT;   // refill when at most this many of th
 #define PT_LEAF_KEEP 3
 #endif
 constexpr int NODE_STEPS = PT_NODE_STEPS, LEAF_STEPS = PT_LEAF_STEPS, LEAF_KEEP = PT_LEAF_KEEP;
+// The box-step loop is unrolled NODE_STEPS times in the kernels whose stacks live entirely in LDS. The spilling variants (scenes walked
+// from global memory, mid-size trees) carry the spill and un-spill paths in every copy, twice (the streams exist in two copies): their
+// unroll count is a parameter of its own (measured: profiles/README.md, round 3)
+#ifndef PT_SPILL_NODE_UNROLL
+#define PT_SPILL_NODE_UNROLL 8
+#endif
 
 // Loads go through address-space-qualified pointers so that the compiler emits ds_read_b128 /
 // global_load_dwordx4 and never a FLAT load: with generic pointers it merged the LDS read of a node
@@ -405,7 +411,8 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
         } else {
             // NODE_STEPS box-pair steps per vote: the vote and the bookkeeping around it cost about half a step
             bool cn = can_node;
-#pragma unroll
+            constexpr int NODE_UNROLL = SPILL ? PT_SPILL_NODE_UNROLL : NODE_STEPS;
+#pragma unroll NODE_UNROLL
             for (int rep = 0; rep < NODE_STEPS; rep++) {
                 UTIL(4, 1); UTIL(5, popc(ballot(cn)));
                 if (cn) {
