@@ -53,4 +53,7 @@ with native.MultiContext([0] * 8, loopback=True) as m:
     out["multi_n8_loopback_one_device"] = {"tile_strip": int(o.tile_strip), "gather_ms_events": round(m.gather_ms(), 3),
                                            "gather_ms_wall": round(wall * 1e3, 3),
                                            "note": "8 contexts share one GPU: only the packing / copies / unpacking are meaningful, not the render time"}
+# RCCL prints a version banner on stdout when it is loaded: the JSON goes to the file named on the command line when there is one
+if len(sys.argv) > 1:
+    json.dump(out, open(sys.argv[1], "w"), indent=1)
 print(json.dumps(out, indent=1))
