@@ -234,6 +234,7 @@ def main():
     ap.add_argument("--worklist", type=int, default=None, help="library option worklist (1: off, 2: per-wave work list of triangle tests in the LDS kernels)")
     ap.add_argument("--tails", type=int, default=None, help="library option tails (1: every kernel its own launch, 2: shadow(b) + extend(b+1) in one traversal launch)")
     ap.add_argument("--state", type=int, default=None, help="library option state (1: ray state in place by path id, 2: it follows the queue)")
+    ap.add_argument("--pipeline", type=int, default=None, help="library option pipeline (1: off, 2: the next batch's raygen on its own stream)")
     ap.add_argument("--keep-reference-tree", action="store_true",
                     help="walk the BVH exactly as uploaded instead of the hierarchy rebuilt over its leaves")
     ap.add_argument("--rehearse", action="store_true",
@@ -322,6 +323,8 @@ def main():
         extra["tails"] = args.tails
     if args.state is not None:
         extra["state"] = args.state
+    if args.pipeline is not None:
+        extra["pipeline"] = args.pipeline
     ctx.set_options(max_bounces=cfg["bounces"], do_mis=mis, frames_per_batch=args.frames_per_batch, traversal=trav, cull=1,
                     timing=args.timing, **extra, **shard.strip_options(world, rank, strip))
 
@@ -391,7 +394,7 @@ def main():
         # same view), so they apply whatever --steps / --warmup are; any flag that changes the dispatch itself rules them out
         is_profiled = (not overridden and world == 1 and args.traversal == "auto"
                        and not args.perf_mode and args.sort is None and args.overlap is None and not args.keep_reference_tree
-                       and args.frames_per_batch == 0 and args.worklist is None and args.tails is None and args.state is None)
+                       and args.frames_per_batch == 0 and args.worklist is None and args.tails is None and args.state is None and args.pipeline is None)
         traffic, traffic_src = pmc_traffic(args.config, is_profiled)
 
         def kernel_entry(label, name, ms, launches, units, bytes_per_unit):
@@ -440,7 +443,7 @@ def main():
                 "traversal": "lds" if st.traversal_used == native.TRAVERSAL_LDS else "global",
                 "triangles": int(len(scene.tris)), "bvh_nodes": int(len(scene.nodes)), "parallelism": par,
                 **({"perf_mode": args.perf_mode} if args.perf_mode else {}),
-                "worklist_used": int(st.worklist_used), "tails_used": int(st.tails_used), "state_used": int(st.state_used),
+                "worklist_used": int(st.worklist_used), "tails_used": int(st.tails_used), "state_used": int(st.state_used), "pipeline_used": int(st.pipeline_used),
             },
             **({"rehearsal": {"sharded_equals_unsharded_bitwise": rehearsal_ok, "backend": "gloo", "note": "all ranks on one GPU; not a benchmark"}} if args.rehearse else {}),
             "segments": int(segments), "shadow_rays": int(shadow_rays), "paths": int(paths),

@@ -99,7 +99,14 @@ typedef struct ptmi_options {
                                    survivors' state at their slot of bounce b's queue into a second set of buffers (+ the path id, for
                                    the radiance), the next queue lists those slots, so the next bounce reads it at the density of ONE
                                    bounce's survival rate. Same arithmetic, same results. 0 = library default */
-    uint32_t reserved[5];
+    uint32_t pipeline;          /* 1 = every batch generates its camera rays on the stream that traces it; 2 = the camera rays of a batch
+                                   are generated on a stream of their own, into a second set of the buffers `raygen` writes (origin /
+                                   direction / radiance, alternating by batch, +48 B per path), as soon as the batch before the previous
+                                   one has been folded — so the write-bound `raygen` of batch k + 1 (1.2 ms per 133 M paths) runs beside the
+                                   last bounces of batch k, whose small queues leave the machine half idle. Applies to consecutive batches
+                                   of one dispatch and to consecutive asynchronous dispatches alike; same kernels, same order of additions,
+                                   same bits. 0 = library default */
+    uint32_t reserved[4];
 } ptmi_options;
 
 typedef struct ptmi_stats {
@@ -132,7 +139,7 @@ typedef struct ptmi_stats {
                                    per-wave work list (ptmi_options.worklist) */
     uint32_t tails_used;        /* ... 1: the last bounces ran on one stream (ptmi_options.tails = 2) */
     uint32_t state_used;        /* ... 1: ray state in place by path id, 2: it followed the queue (ptmi_options.state) */
-    uint32_t reserved_stats;
+    uint32_t pipeline_used;     /* ... 1 / 2: ptmi_options.pipeline as the last dispatch ran (was reserved) */
 } ptmi_stats;
 
 /* ---- lifetime ----------------------------------------------------------- */

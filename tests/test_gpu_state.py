@@ -18,7 +18,7 @@ def st_ctx(gpu_ctx):
     from ptmi import native
     gpu_ctx.set_options(state=2)
     yield gpu_ctx
-    gpu_ctx.set_options(state=0, traversal=native.TRAVERSAL_AUTO, cull=1, keep_reference_tree=0, overlap=2, frames_per_batch=0,
+    gpu_ctx.set_options(state=0, pipeline=0, tails=0, traversal=native.TRAVERSAL_AUTO, cull=1, keep_reference_tree=0, overlap=2, frames_per_batch=0,
                         max_bounces=8, do_mis=1, ray_sort=2, tile_y0=0, tile_y1=0, tile_parts=0)
 
 
@@ -110,3 +110,37 @@ def test_serial_tail_is_invisible(st_ctx, oracle, scene_factory, name, bounces):
         assert (st.segments, st.shadow_rays, st.paths) == (ost.segments, ost.shadow_rays, ost.paths)
         assert_same_floats(got, ref, f"radiance ({name}, {bounces} bounces, state {state})")
     st_ctx.set_options(tails=0)
+
+
+@pytest.mark.parametrize("name,W,H,ap", [("cornell", 96, 64, 0.001), ("feature_box", 72, 72, 0.05)])
+def test_raygen_pipeline_is_invisible(st_ctx, oracle, scene_factory, name, W, H, ap):
+    """ptmi_options.pipeline = 2: batch k + 1's camera rays are generated on their own stream, into the other of two buffer sets,
+    beside batch k. Same kernels, same bits — over many small batches in one dispatch (ragged last batch), over back-to-back
+    asynchronous dispatches of different lengths, with the shadow stream on / off, with the state following the queue, and across
+    switches of the option."""
+    sc = scene_factory(name)
+    frames = 11
+    cam = layout.make_camera(W, H, aperture=ap, focus_distance=2.8)
+    ref, ost = oracle.render(sc, cam, frames, max_bounces=8, do_mis=1)
+    st_ctx.upload_scene(sc)
+    st_ctx.resize(W, H)
+    for overlap, state, fpb in ((1, 1, 2), (0, 1, 3), (1, 2, 2), (1, 1, 0)):
+        st_ctx.set_options(pipeline=2, state=state, tails=0, overlap=overlap, max_bounces=8, do_mis=1, frames_per_batch=fpb)
+        st_ctx.reset_stats()
+        st_ctx.dispatch(cam, frames)                                       # 6 batches of 2 (last: 1), 4 of 3 (last: 2), ..., one of 11
+        got = st_ctx.read_output()
+        st = st_ctx.stats()
+        assert st.pipeline_used == 2
+        assert (st.segments, st.shadow_rays, st.paths) == (ost.segments, ost.shadow_rays, ost.paths)
+        assert_same_floats(got, ref, f"radiance ({name}, overlap {overlap}, state {state}, frames_per_batch {fpb})")
+    # back-to-back dispatches without a synchronisation in between: 1 + 4 + 2 + 3 + 1 frames, the option switched off and on on the way
+    st_ctx.set_options(pipeline=2, state=1, overlap=1, frames_per_batch=2)
+    k = 0
+    for n, pipe in ((1, 2), (4, 2), (2, 1), (3, 2), (1, 2)):
+        st_ctx.set_options(pipeline=pipe)
+        c2 = cam.copy(); c2["frame_index"] = k
+        st_ctx.dispatch(c2, n)
+        k += n
+    assert k == frames
+    assert_same_floats(st_ctx.read_output(), ref, "radiance over five back-to-back dispatches")
+    st_ctx.set_options(pipeline=0)

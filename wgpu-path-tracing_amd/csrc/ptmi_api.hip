@@ -33,6 +33,14 @@ struct Lane {
     DevPaths paths{};
     // second set of ray-state buffers and the path ids of both sets (ptmi_options.state = 2: the state follows the queue)
     float4 *O2 = nullptr, *D2 = nullptr; float2 *C2 = nullptr; uint32_t *pid[2] = {nullptr, nullptr};
+    // ptmi_options.pipeline = 2: a second set of the buffers `raygen` writes (origin + RNG state, direction, radiance); batches alternate
+    // between paths.{O, D, L} and these, and batch k + 1's `raygen` runs on `pre` beside batch k
+    float4 *O_b = nullptr, *D_b = nullptr; float *L_b = nullptr;
+    hipStream_t pre = nullptr;
+    hipEvent_t ev_ray[2] = {nullptr, nullptr};      // recorded on `pre` behind a raygen: the batch's first kernel waits for it
+    hipEvent_t ev_use[2] = {nullptr, nullptr};      // recorded behind a batch's accumulate: its O / D / L may be overwritten
+    bool use_recorded[2] = {false, false};
+    uint64_t pre_seq = 0;                           // batches traced through the pipeline so far (parity = which buffer set)
     float2 *hits = nullptr;
     DevShadow sh[2]{};                                 // shadow records, double-buffered by bounce parity (overlap >= 1)
     uint32_t *queue[2] = {nullptr, nullptr}, *sq[2] = {nullptr, nullptr};
@@ -57,6 +65,7 @@ struct ptmi_ctx {
     Lane lanes[2];
     uint64_t batch_seq = 0;                            // batches launched so far (two lanes: batch k runs on lane k & 1)
     bool last_two_lanes = false;                       // how the previous dispatch used the lanes
+    bool last_pipe = false;                            // ... and whether its camera rays came from the `pre` stream
     mutable std::string err;
     bool alloc_oom = false;                            // the last failed batch allocation ran out of device memory
     ptmi_options opt{};
@@ -88,9 +97,13 @@ namespace {
 
 constexpr int kStatsWords = 8 + 64;
 constexpr int kShadowCount = 72;          // slot of the shadow-queue length in ctx->counts (80 words)
+constexpr int kPipeCount = 76;            // pipeline = 2: slots of the bounce-0 queue length, one per buffer-set parity
 constexpr size_t kLdsMax = 160 * 1024;
 #ifndef PT_STATE_DEFAULT
 #define PT_STATE_DEFAULT 1             /* what ptmi_options.state = 0 means: 1 in place, 2 the state follows the queue (measured: profiles/README.md) */
+#endif
+#ifndef PT_PIPELINE_DEFAULT
+#define PT_PIPELINE_DEFAULT 1          /* what ptmi_options.pipeline = 0 means: 1 off, 2 the next batch's raygen on its own stream (measured: profiles/README.md) */
 #endif
 #ifndef PT_WORKLIST_DEFAULT
 #define PT_WORKLIST_DEFAULT 0          /* what ptmi_options.worklist = 0 means (measured: profiles/README.md) */
@@ -181,6 +194,7 @@ struct Timed {
 void free_batch(Lane &ln) {
     dfree(ln.paths.O); dfree(ln.paths.D); dfree(ln.paths.C); dfree(ln.paths.L);
     dfree(ln.O2); dfree(ln.D2); dfree(ln.C2); dfree(ln.pid[0]); dfree(ln.pid[1]);
+    dfree(ln.O_b); dfree(ln.D_b); dfree(ln.L_b); ln.use_recorded[0] = ln.use_recorded[1] = false;
     dfree(ln.hits);
     for (int k = 0; k < 2; k++) { dfree(ln.sh[k].SO); ln.sh[k].SD = nullptr; ln.sh[k].SC = nullptr; dfree(ln.sq[k]); }
     dfree(ln.queue[0]); dfree(ln.queue[1]); dfree(ln.alive); dfree(ln.shadowm); dfree(ln.octm); dfree(ln.word_off); dfree(ln.d_occ);
@@ -193,6 +207,7 @@ hipError_t sync_all(ptmi_ctx *c) {
     for (Lane &ln : c->lanes) {
         if (e == hipSuccess && ln.main) e = hipStreamSynchronize(ln.main);
         if (e == hipSuccess && ln.side) e = hipStreamSynchronize(ln.side);
+        if (e == hipSuccess && ln.pre) e = hipStreamSynchronize(ln.pre);
     }
     if (e == hipSuccess && c->stream) e = hipStreamSynchronize(c->stream);      // accumulates that waited for a lane
     return e;
@@ -202,9 +217,11 @@ hipError_t sync_all(ptmi_ctx *c) {
 // with the state following the queue a second set of ray state, 40, and two path-id lists)
 constexpr size_t kBytesPerPath = 16 + 16 + 8 + 16 + 8 + 2 * (16 + 16 + sizeof(rgb_sc) + 4) + 2 * 4 + 1 + 1;
 constexpr size_t kBytesPerPathState2 = 16 + 16 + 8 + 2 * 4;
+constexpr size_t kBytesPerPathPipeline = 16 + 16 + 16;
 
-int ensure_capacity(ptmi_ctx *c, Lane &ln, size_t n, bool state2) {
-    if (n <= ln.cap && (!state2 || ln.O2)) return PTMI_OK;
+int ensure_capacity(ptmi_ctx *c, Lane &ln, size_t n, bool state2, bool pipe = false) {
+    if (n <= ln.cap && (!state2 || ln.O2) && (!pipe || ln.O_b)) return PTMI_OK;
+    state2 = state2 || ln.O2; pipe = pipe || ln.O_b;         // what the lane had, it keeps
     if (n < ln.cap) n = ln.cap;
     HIP_TRY(c, sync_all(c));
     free_batch(ln);
@@ -219,6 +236,7 @@ int ensure_capacity(ptmi_ctx *c, Lane &ln, size_t n, bool state2) {
         return fail(c, PTMI_E_HIP, "hipMalloc of %zu bytes for a batch of %zu paths failed: %s", (size_t)(bytes), cap, hipGetErrorString(e_)); } } while (0)
     ALLOC(ln.paths.O, cap * 16); ALLOC(ln.paths.D, cap * 16);
     ALLOC(ln.paths.C, cap * 8); ALLOC(ln.paths.L, cap * 16);      // room for either stride
+    if (pipe) { ALLOC(ln.O_b, cap * 16); ALLOC(ln.D_b, cap * 16); ALLOC(ln.L_b, cap * 16); }
     if (state2) { ALLOC(ln.O2, cap * 16); ALLOC(ln.D2, cap * 16); ALLOC(ln.C2, cap * 8); ALLOC(ln.pid[0], cap * 4); ALLOC(ln.pid[1], cap * 4); }
     ALLOC(ln.hits, cap * 8);
     for (int k = 0; k < 2; k++) {
@@ -497,7 +515,13 @@ int ptmi_create(int device_ordinal, ptmi_ctx **out) {
 #else
             ok = ok && hipStreamCreateWithFlags(&ln.side, hipStreamNonBlocking) == hipSuccess;
 #endif
-            for (hipEvent_t *e : {&ln.ev_ready, &ln.ev_shadow[0], &ln.ev_shadow[1], &ln.ev_mid, &ln.ev_done, &ln.ev_free})
+            // The `pre` stream (ptmi_options.pipeline) is created at the LOWEST priority, for two reasons: its `raygen` is meant to fill
+            // idle wave slots, never to take them; and the runtime multiplexes streams of one priority onto a few hardware queues
+            // (4 by default) — a normal-priority `pre` landed on the caller's own queue and ran in order behind its kernels
+            // (profiles/r03_pipeline/timeline_same_queue.txt) — while another priority level has hardware queues of its own.
+            ok = ok && hipStreamCreateWithPriority(&ln.pre, hipStreamNonBlocking, lo) == hipSuccess;
+            for (hipEvent_t *e : {&ln.ev_ready, &ln.ev_shadow[0], &ln.ev_shadow[1], &ln.ev_mid, &ln.ev_done, &ln.ev_free,
+                                  &ln.ev_ray[0], &ln.ev_ray[1], &ln.ev_use[0], &ln.ev_use[1]})
                 ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
             ok = ok && hipMalloc(&ln.counts, 80 * sizeof(uint32_t)) == hipSuccess;
         }
@@ -521,7 +545,9 @@ int ptmi_destroy(ptmi_ctx *c) {
     for (Lane &ln : c->lanes) {
         free_batch(ln);
         dfree(ln.counts); dfree(ln.d_spill); dfree(ln.d_spill_side);
-        for (hipEvent_t e : {ln.ev_ready, ln.ev_shadow[0], ln.ev_shadow[1], ln.ev_mid, ln.ev_done, ln.ev_free}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {ln.ev_ready, ln.ev_shadow[0], ln.ev_shadow[1], ln.ev_mid, ln.ev_done, ln.ev_free,
+                             ln.ev_ray[0], ln.ev_ray[1], ln.ev_use[0], ln.ev_use[1]}) if (e) (void)hipEventDestroy(e);
+        if (ln.pre) (void)hipStreamDestroy(ln.pre);
         if (ln.side) (void)hipStreamDestroy(ln.side);
         if (ln.main) (void)hipStreamDestroy(ln.main);
     }
@@ -648,6 +674,7 @@ int ptmi_set_options(ptmi_ctx *c, const ptmi_options *o) {
     if (o->worklist > 2) return fail(c, PTMI_E_INVALID, "unknown worklist %u", o->worklist);
     if (o->tails > 2) return fail(c, PTMI_E_INVALID, "unknown tails %u", o->tails);
     if (o->state > 2) return fail(c, PTMI_E_INVALID, "unknown state %u", o->state);
+    if (o->pipeline > 2) return fail(c, PTMI_E_INVALID, "unknown pipeline %u", o->pipeline);
     c->opt = *o;
     return PTMI_OK;
 }
@@ -673,6 +700,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     // (measured at 1080p, Msamples/s: 32 frames 8 920, 64 frames 9 150 - 9 275, 128 frames 9 270 - 9 310)
     const bool auto_F = F == 0;
     const bool state2 = (c->opt.state ? c->opt.state : (uint32_t)PT_STATE_DEFAULT) == 2u;
+    const bool want_pipe = (c->opt.pipeline ? c->opt.pipeline : (uint32_t)PT_PIPELINE_DEFAULT) == 2u && c->opt.overlap != 3;
     if (auto_F) {
         F = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, (128ull << 20) / npix));
         // ... but never more than the device has room for: several contexts may share one device (ranks rehearsed on one GPU, a
@@ -680,10 +708,10 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
         // Room = free memory + what this context's lanes already hold, less a tenth for the rest (spill areas, blit staging).
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const uint64_t held = (uint64_t)c->lanes[0].cap * (kBytesPerPath + (c->lanes[0].O2 ? kBytesPerPathState2 : 0)) +
-                                  (uint64_t)c->lanes[1].cap * (kBytesPerPath + (c->lanes[1].O2 ? kBytesPerPathState2 : 0));
+            auto per_path = [](const Lane &l) { return kBytesPerPath + (l.O2 ? kBytesPerPathState2 : 0) + (l.O_b ? kBytesPerPathPipeline : 0); };
+            const uint64_t held = (uint64_t)c->lanes[0].cap * per_path(c->lanes[0]) + (uint64_t)c->lanes[1].cap * per_path(c->lanes[1]);
             const uint64_t room = (uint64_t)((double)(free_b + held) * 0.9);
-            const uint64_t fit = room / (npix * (kBytesPerPath + (state2 ? kBytesPerPathState2 : 0)));
+            const uint64_t fit = room / (npix * (kBytesPerPath + (state2 ? kBytesPerPathState2 : 0) + (want_pipe ? kBytesPerPathPipeline : 0)));
             F = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(F, fit));
         }
     }
@@ -711,9 +739,11 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     if (c->opt.traversal == PTMI_TRAVERSAL_LDS && cfg0.variant != PT_VARIANT_LDS)
         return fail(c, PTMI_E_UNSUPPORTED, "scene needs %zu B of LDS plus the stack; it does not fit in %zu B", c->lds_scene_bytes, kLdsMax);
     if (two_lanes != c->last_two_lanes) { HIP_TRY(c, sync_all(c)); c->last_two_lanes = two_lanes; }     // lane 0 changes streams
+    // (the same when the pipeline is switched on or off: a `raygen` on the `pre` stream is only ordered against pipelined batches)
+    if ((want_pipe && !two_lanes) != c->last_pipe) { HIP_TRY(c, sync_all(c)); c->last_pipe = want_pipe && !two_lanes; }
     for (;;) {
         rc = PTMI_OK;
-        for (int k = 0; k < (two_lanes ? 2 : 1) && rc == PTMI_OK; k++) rc = ensure_capacity(c, c->lanes[k], (size_t)(npix * Fsub), state2);
+        for (int k = 0; k < (two_lanes ? 2 : 1) && rc == PTMI_OK; k++) rc = ensure_capacity(c, c->lanes[k], (size_t)(npix * Fsub), state2, want_pipe);
         if (rc == PTMI_OK) break;
         // out of device memory with a batch size the library chose: halve it and try again (hipMemGetInfo is a snapshot; another
         // context may have allocated since). A size the caller asked for fails loudly.
@@ -735,6 +765,8 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     c->st.worklist_used = (cfg0.worklist ? 1u : 0u) | ((nee && cfg_shadow0.worklist) ? 2u : 0u);
     c->st.state_used = state2 ? 2u : 1u;
     c->st.tails_used = (side && serial_tail) ? 1u : 0u;
+    const bool pipe = want_pipe && !two_lanes;
+    c->st.pipeline_used = pipe ? 2u : 1u;
     c->st.radiance_stride_bytes = 4u * (PT_L_STRIDE ? (uint32_t)PT_L_STRIDE : ((cfg0.quantized || cfg_shadow0.quantized) ? 4u : 3u));
     const int blocks = c->n_cu * 8;
 #ifndef PT_SHADE_WGS_PER_CU
@@ -765,13 +797,36 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
                 if (ln.free_recorded) HIP_TRY(c, hipStreamWaitEvent(ms, ln.ev_free, 0));            // its buffers were folded
                 if (other.mid_recorded) HIP_TRY(c, hipStreamWaitEvent(ms, other.ev_mid, 0));        // the stagger
             }
-            { Timed t(c, 4, t3, ms); pt_launch_raygen(ms, blocks, *cam, band, frame0, fb, ln.paths, &ln.counts[0]); }
+            // pipeline = 2: this batch's camera rays go to the buffer set of its parity, on the lane's `pre` stream, as soon as the
+            // batch that last used that set (two batches ago) has been folded — i.e. beside the batch before this one, which is
+            // still being traced when this call enqueues; the batch's own kernels wait for them. The bounce-0 queue length that
+            // `raygen` leaves has a slot per parity too (the previous batch may still be reading its own).
+            const int pp = pipe ? (int)(ln.pre_seq++ & 1u) : 0;
+            DevPaths bp = ln.paths;
+            if (pp) { bp.O = ln.O_b; bp.D = ln.D_b; bp.L = ln.L_b; }
+            uint32_t *const count0 = pipe ? &ln.counts[kPipeCount + pp] : &ln.counts[0];
+            auto cnt = [&](uint32_t b) -> uint32_t * { return b == 0u ? count0 : &ln.counts[b]; };
+            if (pipe) {
+                if (ln.use_recorded[pp]) HIP_TRY(c, hipStreamWaitEvent(ln.pre, ln.ev_use[pp], 0));
+                // ... and not before the previous batch has compacted bounce 3: released at once, `raygen` would only take the
+                // machine from that batch's first bounces (measured: +-0); from bounce 4 on the queues are a tenth and the write-bound
+                // `raygen` finds idle wave slots and an idle memory system
+#ifndef PT_PIPELINE_HOLD
+#define PT_PIPELINE_HOLD 1
+#endif
+                if (PT_PIPELINE_HOLD && ln.mid_recorded) HIP_TRY(c, hipStreamWaitEvent(ln.pre, ln.ev_mid, 0));
+                { Timed t(c, 4, t3, ln.pre); pt_launch_raygen(ln.pre, blocks, *cam, band, frame0, fb, bp, count0); }
+                HIP_TRY(c, hipEventRecord(ln.ev_ray[pp], ln.pre));
+                HIP_TRY(c, hipStreamWaitEvent(ms, ln.ev_ray[pp], 0));
+            } else {
+                Timed t(c, 4, t3, ms); pt_launch_raygen(ms, blocks, *cam, band, frame0, fb, bp, count0);
+            }
             int cur = 0;
             const uint32_t mid_bounce = std::min(3u, maxb - 1u);
             // state = 2: the rays of bounce b live in set A (ln.paths) for b <= 1 and odd b, in set B (O2, D2, C2) for even b >= 2,
             // at the index the queue gives: the path id up to bounce 1 (bounce 0 writes in place: its slots ARE the path ids), from
             // then on the ray's slot in the previous bounce's queue. shade(b) reads set(b) and writes set(b + 1) at its own slots.
-            DevPaths setA = ln.paths, setB = ln.paths;
+            DevPaths setA = bp, setB = bp;
             setB.O = ln.O2; setB.D = ln.D2; setB.C = ln.C2;
             for (uint32_t b = 0; b < maxb; b++) {
                 const uint32_t *q = b == 0 ? nullptr : ln.queue[cur];      // bounce 0: slot i holds path i
@@ -786,37 +841,37 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
                     shp.pid_out = b >= 1u ? ln.pid[out_b ? 1 : 0] : nullptr;
                 }
                 const uint32_t *cq = state2 ? nullptr : q;                 // what compaction lists: the slots themselves / their path ids
-                { Timed t(c, 1, t2, ms); pt_launch_extend(ms, blocks, cfg, c->sc, pin, q, &ln.counts[b], ln.hits); }
+                { Timed t(c, 1, t2, ms); pt_launch_extend(ms, blocks, cfg, c->sc, pin, q, cnt(b), ln.hits); }
                 const bool last = b + 1 == maxb;
                 uint64_t *octm = (sort && !last) ? ln.octm : nullptr;
                 if (side && b >= 2) HIP_TRY(c, hipStreamWaitEvent(ms, ln.ev_shadow[par], 0));      // its records are read
                 shp.octant_masks = octm;
                 { Timed t(c, 2, t3, ms);
                   (c->opt.perf_mode ? pt_launch_shade_fast : pt_launch_shade)(
-                      ms, shade_blocks, c->sc, pin, q, &ln.counts[b], ln.hits, ln.sh[par], ln.alive, ln.shadowm, shp); }
+                      ms, shade_blocks, c->sc, pin, q, cnt(b), ln.hits, ln.sh[par], ln.alive, ln.shadowm, shp); }
                 { Timed t(c, 5, t3, ms);
-                  pt_launch_compact(ms, tiles, cq, &ln.counts[b], ln.alive, nee ? ln.shadowm : nullptr,
+                  pt_launch_compact(ms, tiles, cq, cnt(b), ln.alive, nee ? ln.shadowm : nullptr,
                                     ln.word_off, ln.queue[cur ^ 1], &ln.counts[b + 1], ln.sq[par], &ln.counts[kShadowCount + par],
                                     c->d_stats, b, last ? 0 : 1, octm, (uint32_t)ln.mask_words); }
-                if (two_lanes && b == mid_bounce) { HIP_TRY(c, hipEventRecord(ln.ev_mid, ms)); ln.mid_recorded = true; }
+                if ((two_lanes || pipe) && b == mid_bounce) { HIP_TRY(c, hipEventRecord(ln.ev_mid, ms)); ln.mid_recorded = true; }
                 if (side && serial_tail && b >= kTailBounce) {
                     // tails = 2: the small queues of the last bounces on ONE stream, every kernel by itself. `shadow` stays the only
                     // kernel that adds to L and keeps its bounce order: the first one here waits for the side stream's last one.
                     if (b == kTailBounce) HIP_TRY(c, hipStreamWaitEvent(ms, ln.ev_shadow[(b - 1u) & 1u], 0));
                     { Timed t(c, 3, t3, ms);
-                      pt_launch_shadow(ms, blocks, cfg_shadow, c->sc, ln.paths, ln.sh[par], ln.sq[par],
+                      pt_launch_shadow(ms, blocks, cfg_shadow, c->sc, bp, ln.sh[par], ln.sq[par],
                                        &ln.counts[kShadowCount + par], nullptr); }
                     HIP_TRY(c, hipEventRecord(ln.ev_shadow[par], ms));
                 } else if (side) {
                     HIP_TRY(c, hipEventRecord(ln.ev_ready, ms));
                     HIP_TRY(c, hipStreamWaitEvent(ss, ln.ev_ready, 0));
                     { Timed t(c, 3, t3, ss);
-                      pt_launch_shadow(ss, blocks, cfg_shadow, c->sc, ln.paths, ln.sh[par], ln.sq[par],
+                      pt_launch_shadow(ss, blocks, cfg_shadow, c->sc, bp, ln.sh[par], ln.sq[par],
                                        &ln.counts[kShadowCount + par], nullptr); }
                     HIP_TRY(c, hipEventRecord(ln.ev_shadow[par], ss));
                 } else if (nee) {
                     Timed t(c, 3, t3, ms);
-                    pt_launch_shadow(ms, blocks, cfg_shadow, c->sc, ln.paths, ln.sh[0], ln.sq[0], &ln.counts[kShadowCount], nullptr);
+                    pt_launch_shadow(ms, blocks, cfg_shadow, c->sc, bp, ln.sh[0], ln.sq[0], &ln.counts[kShadowCount], nullptr);
                 }
                 cur ^= 1;
             }
@@ -830,7 +885,8 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
                 HIP_TRY(c, hipEventRecord(ln.ev_done, ms));
                 HIP_TRY(c, hipStreamWaitEvent(as, ln.ev_done, 0));
             }
-            { Timed t(c, 6, t3, as); pt_launch_accumulate(as, blocks, band, frame0, fb, ln.paths.L, ln.paths.l_stride, c->d_out); }
+            { Timed t(c, 6, t3, as); pt_launch_accumulate(as, blocks, band, frame0, fb, bp.L, bp.l_stride, c->d_out); }
+            if (pipe) { HIP_TRY(c, hipEventRecord(ln.ev_use[pp], as)); ln.use_recorded[pp] = true; }
             if (two_lanes) { HIP_TRY(c, hipEventRecord(ln.ev_free, as)); ln.free_recorded = true; }
         }
     }

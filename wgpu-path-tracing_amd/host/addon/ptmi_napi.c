@@ -168,6 +168,7 @@ static void read_options(napi_env env, napi_value obj, ptmi_options *o) {
     o->worklist = get_u32_prop(env, obj, "worklist", o->worklist);
     o->tails = get_u32_prop(env, obj, "tails", o->tails);
     o->state = get_u32_prop(env, obj, "state", o->state);
+    o->pipeline = get_u32_prop(env, obj, "pipeline", o->pipeline);
 }
 
 static napi_value js_set_options(napi_env env, napi_callback_info info) {

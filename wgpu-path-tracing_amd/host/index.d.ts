@@ -36,6 +36,8 @@ export interface TraceOptions {
   tails?: 0 | 1 | 2;
   /** 0 (library default) / 1 ray state in place by path id / 2 the state follows the queue (denser gathers in late bounces) */
   state?: 0 | 1 | 2;
+  /** 0 (library default) / 1 off / 2 the next batch's camera rays are generated on their own stream beside this batch's last bounces */
+  pipeline?: 0 | 1 | 2;
 }
 export interface Stats {
   paths: number; segments: number; shadowRays: number; frames: number; dispatches: number;

@@ -46,7 +46,7 @@ class Options(ctypes.Structure):
                 ("tile_parts", ctypes.c_uint32), ("tile_part", ctypes.c_uint32), ("tile_strip", ctypes.c_uint32),
                 ("perf_mode", ctypes.c_uint32), ("ray_sort", ctypes.c_uint32), ("overlap", ctypes.c_uint32),
                 ("worklist", ctypes.c_uint32), ("tails", ctypes.c_uint32), ("state", ctypes.c_uint32),
-                ("reserved", ctypes.c_uint32 * 5)]
+                ("pipeline", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 4)]
 
 
 class Stats(ctypes.Structure):
@@ -61,7 +61,7 @@ class Stats(ctypes.Structure):
                 ("raygen_ms", ctypes.c_double), ("compact_ms", ctypes.c_double), ("accumulate_ms", ctypes.c_double),
                 ("upload_ms", ctypes.c_double), ("upload_tree_ms", ctypes.c_double), ("upload_copy_ms", ctypes.c_double),
                 ("worklist_used", ctypes.c_uint32), ("tails_used", ctypes.c_uint32),
-                ("state_used", ctypes.c_uint32), ("reserved_stats", ctypes.c_uint32)]
+                ("state_used", ctypes.c_uint32), ("pipeline_used", ctypes.c_uint32)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("segments_by_bounce", "reserved", "reserved_stats")}
