@@ -121,13 +121,15 @@ struct TraverseConfig {
     int wants_spill;        // the variant needs one (the caller supplies `spill`: each concurrently running kernel its own)
     int quantized;          // global variant: walk the quantised image when the scene has one
     int worklist;           // LDS variant: triangle tests through the per-wave work list (traverse.hip trace_wave_wl)
+    uint32_t *ticket;       // -DPT_DYNAMIC_CLAIM builds: this launch's chunk counter (one zeroed word in device memory); else unused
 };
 #ifndef PT_QCACHE_NODES
 #define PT_QCACHE_NODES 256      /* quantised nodes of the top levels staged in LDS per workgroup (8 KB) */
 #endif
 #define PT_SPILL_ENTRIES 64     /* >= the deepest node stack: upload rejects trees deeper than 62 */
 size_t pt_spill_bytes(int blocks);
-size_t pt_worklist_bytes(void);  // LDS a 1024-thread workgroup needs for its waves' work lists
+size_t pt_worklist_bytes(void);
+int pt_dynamic_claim(void);     // 1 in -DPT_DYNAMIC_CLAIM builds: every traversal launch needs TraverseConfig::ticket  // LDS a 1024-thread workgroup needs for its waves' work lists
 
 // ---- launchers (each enqueues on `s`; grids are persistent, sized by the caller) ----
 void pt_launch_raygen(hipStream_t s, int blocks, const ptmi_camera &cam, DevBand band, uint32_t frame0,

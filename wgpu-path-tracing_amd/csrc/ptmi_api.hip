@@ -47,6 +47,7 @@ struct Lane {
     uint64_t *alive = nullptr, *shadowm = nullptr, *octm = nullptr;   // octm: 3 x words (ray_sort)
     size_t mask_words = 0;
     uint32_t *word_off = nullptr, *counts = nullptr;
+    uint32_t *tickets = nullptr;          // -DPT_DYNAMIC_CLAIM builds: one chunk counter per traversal launch of a batch (zeroed per batch)
     uint32_t *d_spill = nullptr;          // node-stack overflow of the global traversal variant (128 MiB on 256 CUs; first use)
     uint32_t *d_spill_side = nullptr;     // ... of the `shadow` kernel when it runs beside `extend`
     uint8_t *d_occ = nullptr;
@@ -97,6 +98,7 @@ namespace {
 
 constexpr int kStatsWords = 8 + 64;
 constexpr int kShadowCount = 72;          // slot of the shadow-queue length in ctx->counts (80 words)
+constexpr int kTickets = 160;             // per lane: extend(b) uses word b, shadow(b) word 64 + b, the per-stage entry points word 159
 constexpr int kPipeCount = 76;            // pipeline = 2: slots of the bounce-0 queue length, one per buffer-set parity
 constexpr size_t kLdsMax = 160 * 1024;
 #ifndef PT_STATE_DEFAULT
@@ -524,6 +526,7 @@ int ptmi_create(int device_ordinal, ptmi_ctx **out) {
                                   &ln.ev_ray[0], &ln.ev_ray[1], &ln.ev_use[0], &ln.ev_use[1]})
                 ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
             ok = ok && hipMalloc(&ln.counts, 80 * sizeof(uint32_t)) == hipSuccess;
+            ok = ok && hipMalloc(&ln.tickets, kTickets * sizeof(uint32_t)) == hipSuccess;
         }
         if (!ok) { ptmi_destroy(c); return fail(nullptr, PTMI_E_HIP, "stream / event creation failed"); }
     }
@@ -544,7 +547,7 @@ int ptmi_destroy(ptmi_ctx *c) {
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     for (Lane &ln : c->lanes) {
         free_batch(ln);
-        dfree(ln.counts); dfree(ln.d_spill); dfree(ln.d_spill_side);
+        dfree(ln.counts); dfree(ln.tickets); dfree(ln.d_spill); dfree(ln.d_spill_side);
         for (hipEvent_t e : {ln.ev_ready, ln.ev_shadow[0], ln.ev_shadow[1], ln.ev_mid, ln.ev_done, ln.ev_free,
                              ln.ev_ray[0], ln.ev_ray[1], ln.ev_use[0], ln.ev_use[1]}) if (e) (void)hipEventDestroy(e);
         if (ln.pre) (void)hipStreamDestroy(ln.pre);
@@ -801,6 +804,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
             // batch that last used that set (two batches ago) has been folded — i.e. beside the batch before this one, which is
             // still being traced when this call enqueues; the batch's own kernels wait for them. The bounce-0 queue length that
             // `raygen` leaves has a slot per parity too (the previous batch may still be reading its own).
+            if (pt_dynamic_claim()) HIP_TRY(c, hipMemsetAsync(ln.tickets, 0, kTickets * sizeof(uint32_t), ms));
             const int pp = pipe ? (int)(ln.pre_seq++ & 1u) : 0;
             DevPaths bp = ln.paths;
             if (pp) { bp.O = ln.O_b; bp.D = ln.D_b; bp.L = ln.L_b; }
@@ -841,6 +845,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
                     shp.pid_out = b >= 1u ? ln.pid[out_b ? 1 : 0] : nullptr;
                 }
                 const uint32_t *cq = state2 ? nullptr : q;                 // what compaction lists: the slots themselves / their path ids
+                cfg.ticket = ln.tickets + b; cfg_shadow.ticket = ln.tickets + 64 + b;
                 { Timed t(c, 1, t2, ms); pt_launch_extend(ms, blocks, cfg, c->sc, pin, q, cnt(b), ln.hits); }
                 const bool last = b + 1 == maxb;
                 uint64_t *octm = (sort && !last) ? ln.octm : nullptr;
@@ -1063,6 +1068,7 @@ int ptmi_debug_intersect(ptmi_ctx *c, uint32_t n, const float *o3, const float *
         return fail(c, PTMI_E_UNSUPPORTED, "scene does not fit in LDS");
     if (cfg.wants_spill && !ln.d_spill) HIP_TRY(c, hipMalloc(&ln.d_spill, pt_spill_bytes(c->n_cu * 8)));
     cfg.spill = ln.d_spill;
+    if (pt_dynamic_claim()) { HIP_TRY(c, hipMemsetAsync(ln.tickets + kTickets - 1, 0, sizeof(uint32_t), c->stream)); cfg.ticket = ln.tickets + kTickets - 1; }
     c->st.worklist_used = cfg.worklist ? 1u : 0u;
     pt_launch_extend(c->stream, c->n_cu * 8, cfg, c->sc, ln.paths, nullptr, &ln.counts[0], ln.hits);
     // (u, v) are not part of the hit record: rebuilt exactly as `shade` rebuilds them (into the C stream, unused here)
@@ -1099,6 +1105,7 @@ int ptmi_debug_occluded(ptmi_ctx *c, uint32_t n, const float *o3, const float *d
     TraverseConfig cfg = traverse_config(c, false);
     if (cfg.wants_spill && !ln.d_spill) HIP_TRY(c, hipMalloc(&ln.d_spill, pt_spill_bytes(c->n_cu * 8)));
     cfg.spill = ln.d_spill;
+    if (pt_dynamic_claim()) { HIP_TRY(c, hipMemsetAsync(ln.tickets + kTickets - 1, 0, sizeof(uint32_t), c->stream)); cfg.ticket = ln.tickets + kTickets - 1; }
     c->st.worklist_used = cfg.worklist ? 2u : 0u;
     pt_launch_shadow(c->stream, c->n_cu * 8, cfg, c->sc, ln.paths, ln.sh[0], nullptr, &ln.counts[0], ln.d_occ);
     HIP_TRY(c, hipMemcpyAsync(occ, ln.d_occ, n, hipMemcpyDeviceToHost, c->stream));

@@ -293,19 +293,31 @@ struct OccludedIO {
 // accesses coalesce) and goes on with an empty one; when the LDS part runs dry it takes the last 8 spilled entries
 // back. Deep trees then need no deeper LDS stacks — the occupancy of a depth-60 scene is that of a depth-14 one — and
 // the order in which nodes are visited, hence every result, is unchanged.
+// -DPT_DYNAMIC_CLAIM=1 (an experiment, profiles/README.md round 3): instead of the fixed share above a wave CLAIMS chunks of consecutive
+// slots with one atomic each (about 8 chunks per wave of a full grid), so that a workgroup that becomes resident late — because another
+// kernel holds part of the machine when this one launches — finds less work left instead of a full share to run as a second round.
+#ifndef PT_DYNAMIC_CLAIM
+#define PT_DYNAMIC_CLAIM 0
+#endif
 template <int MODE, bool CULL, int STACK, bool SPILL, int REFILL, class Mem, class IO>
 PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t count, uint32_t gw,
                              uint32_t total_waves, uint32_t *stk, int stride, uint32_t *spill = nullptr,
-                             uint32_t spill_lanes = 0) {
+                             uint32_t spill_lanes = 0, uint32_t *ticket = nullptr) {
     constexpr bool ANY = MODE == MODE_SHADOW;
     constexpr int NODE_KEEP = ANY ? 2 : 3;
     const uint32_t lane = threadIdx.x & 63u;
     // gw (and so end, next) is the same in all 64 lanes; readfirstlane tells the compiler, which then keeps
     // the queue bookkeeping in SGPRs and turns the refill / exit tests into scalar branches
     gw = uniform(gw);
+#if PT_DYNAMIC_CLAIM
+    // the slots [cpos, cend) of the claimed chunk are still to be handed out; cpos = PT_REF_NONE: the ticket counter has run out.
+    // (Two scalar registers and the counter's address: the kernels that share a CU between two workgroups have 80 in all.)
+    uint32_t cpos = 0u, cend = 0u;
+#else
     const uint32_t ngroups = (count + 63u) >> 6;
     const uint32_t end = gw < ngroups ? ((ngroups - gw + total_waves - 1u) / total_waves) * 64u : 0u;
     uint32_t next = 0u;
+#endif
     bool active = false, slow = false;      // slow: an irregular ray or an unbounded determinant, see the refill
     const bool has_fast = sc.has_fast != 0u;
     uint32_t slot = 0, cur = PT_REF_NONE;
@@ -323,12 +335,30 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
 
     for (;;) {
         uint64_t act = ballot(active);
+#if PT_DYNAMIC_CLAIM
+        if (cpos >= cend && cpos != PT_REF_NONE && popc(act) <= REFILL) {      // claim the next chunk: one atomic for the wave
+            uint32_t chunk = uniform(((count / (total_waves * 8u)) + 63u) & ~63u);      // about 8 chunks per wave of a full grid, at least 256 slots
+            chunk = chunk < 256u ? 256u : chunk;
+            uint32_t t = 0u;
+            if (lane == 0u) t = atomicAdd(ticket, 1u);
+            t = uniform(t);
+            const unsigned long long base = (unsigned long long)t * chunk;
+            if (base >= count) { cpos = PT_REF_NONE; cend = 0u; }
+            else { cpos = (uint32_t)base; cend = (base + chunk < count) ? (uint32_t)(base + chunk) : count; }
+        }
+        if (cpos < cend && popc(act) <= REFILL) {
+            const uint64_t idle = ~act;
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            const uint32_t vslot = cpos + rank;
+            if (!active && vslot < cend) {
+#else
         if (next < end && popc(act) <= REFILL) {
             const uint64_t idle = ~act;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             const uint32_t vi = next + rank;
             const uint32_t vslot = ((vi >> 6) * total_waves + gw) * 64u + (vi & 63u);
             if (!active && vi < end && vslot < count) {
+#endif
                 slot = vslot;
                 const bool want = io.fetch(slot, o, d, tlim);
                 inv = mk3(rcp1(d.x), rcp1(d.y), rcp1(d.z));
@@ -355,11 +385,20 @@ PT_DEV void trace_wave(const Mem &m, const DevScene &sc, const IO &io, uint32_t 
                     io.finish(slot, best, false);
                 }
             }
+#if PT_DYNAMIC_CLAIM
+            cpos += (uint32_t)__popcll(idle);
+            cpos = cpos < cend ? cpos : cend;
+#else
             next += (uint32_t)__popcll(idle);
+#endif
             UTIL(2, 1); UTIL(3, popc(ballot(active)) - popc(act));
             act = ballot(active);
         }
+#if PT_DYNAMIC_CLAIM
+        if (act == 0ull) { if (cpos == PT_REF_NONE) break; if (cpos >= cend) continue; }
+#else
         if (act == 0ull && next >= end) break;
+#endif
         UTIL(0, 1); UTIL(1, popc(act));
 
         // two entries free (a step files at most two entries) — or, with SPILL, two free once the node entries are moved out
@@ -722,7 +761,7 @@ constexpr int GBLOCK = 256;
 #endif
 template <int MODE, bool CULL, int STACK, bool QUANT, class IO>
 __global__ __launch_bounds__(GBLOCK) PT_GLOBAL_ATTR void k_trace_global(DevScene sc, IO io, const uint32_t *__restrict__ count_ptr,
-                                                         uint32_t *__restrict__ spill) {
+                                                         uint32_t *__restrict__ spill, uint32_t *ticket) {
     __shared__ uint32_t stk[STACK * GBLOCK];
     const uint32_t count = *count_ptr;
     const uint32_t gw = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;       // consecutive groups -> different workgroups
@@ -739,11 +778,11 @@ __global__ __launch_bounds__(GBLOCK) PT_GLOBAL_ATTR void k_trace_global(DevScene
         QuantMem m{(glb_u4p)sc.qnodes, (glb_u32p)sc.leaf_stream, (glb_f4p)sc.tripos,
                    sc.q_origin[0], sc.q_origin[1], sc.q_origin[2], sc.q_scale[0], sc.q_scale[1], sc.q_scale[2],
                    (lds_u4p)qcache, nc};
-        trace_wave<MODE, CULL, STACK, true, PT_REFILL_GLOBAL>(m, sc, io, count, gw, gridDim.x * (GBLOCK / 64), stk + threadIdx.x, GBLOCK, sp, gridDim.x * GBLOCK);
+        trace_wave<MODE, CULL, STACK, true, PT_REFILL_GLOBAL>(m, sc, io, count, gw, gridDim.x * (GBLOCK / 64), stk + threadIdx.x, GBLOCK, sp, gridDim.x * GBLOCK, ticket);
     } else {
         if (gw * 64u >= count) return;
         GlobalMem m{(glb_f4p)sc.wnodes, (glb_f4p)sc.tripos};
-        trace_wave<MODE, CULL, STACK, true, PT_REFILL_GLOBAL>(m, sc, io, count, gw, gridDim.x * (GBLOCK / 64), stk + threadIdx.x, GBLOCK, sp, gridDim.x * GBLOCK);
+        trace_wave<MODE, CULL, STACK, true, PT_REFILL_GLOBAL>(m, sc, io, count, gw, gridDim.x * (GBLOCK / 64), stk + threadIdx.x, GBLOCK, sp, gridDim.x * GBLOCK, ticket);
     }
 }
 
@@ -758,9 +797,17 @@ __global__ __launch_bounds__(GBLOCK) PT_GLOBAL_ATTR void k_trace_global(DevScene
 // triangle and miss the LDS-resident triangles); ptmi_api picks per kernel.
 constexpr int LBLOCK = 1024;
 
+#ifndef PT_LDS_WAVES
+#define PT_LDS_WAVES 0             /* > 0: ask the register allocator for at least that many waves per SIMD (8 = two 1024-thread workgroups per CU) */
+#endif
+#if PT_LDS_WAVES > 0
+#define PT_LDS_ATTR __attribute__((amdgpu_waves_per_eu(PT_LDS_WAVES)))
+#else
+#define PT_LDS_ATTR
+#endif
 template <int MODE, bool CULL, int STACK, bool TRIS_IN_LDS, bool SPILL, bool WL, class IO>
-__global__ __launch_bounds__(LBLOCK) void k_trace_lds(DevScene sc, IO io, const uint32_t *__restrict__ count_ptr,
-                                                      uint32_t *__restrict__ spill) {
+__global__ __launch_bounds__(LBLOCK) PT_LDS_ATTR void k_trace_lds(DevScene sc, IO io, const uint32_t *__restrict__ count_ptr,
+                                                      uint32_t *__restrict__ spill, uint32_t *ticket) {
     extern __shared__ float4 smem[];
     const uint32_t count = *count_ptr;
     if (blockIdx.x * 64u >= count) return;      // wave 0 owns group blockIdx.x; if that is empty the whole group is idle
@@ -778,9 +825,12 @@ __global__ __launch_bounds__(LBLOCK) void k_trace_lds(DevScene sc, IO io, const 
         trace_wave_wl<MODE, CULL, STACK, REFILL_AT>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk, LBLOCK, wl);
     } else {
         trace_wave<MODE, CULL, STACK, SPILL, REFILL_AT>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk, LBLOCK,
-                                             SPILL ? spill + (size_t)blockIdx.x * LBLOCK + threadIdx.x : nullptr, gridDim.x * LBLOCK);
+                                             SPILL ? spill + (size_t)blockIdx.x * LBLOCK + threadIdx.x : nullptr, gridDim.x * LBLOCK, ticket);
     }
 }
+
+// the ticket counter of the launch being enqueued (PT_DYNAMIC_CLAIM builds; set by launch() from TraverseConfig::ticket)
+thread_local uint32_t *g_ticket = nullptr;
 
 template <int MODE, bool CULL, int STACK, bool TRIS, bool SPILL = false, bool WL = false, class IO>
 void launch_lds(hipStream_t s, int wgs, size_t bytes, const DevScene &sc, const IO &io, const uint32_t *count,
@@ -795,7 +845,7 @@ void launch_lds(hipStream_t s, int wgs, size_t bytes, const DevScene &sc, const 
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         raised.fetch_or(bit, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((k_trace_lds<MODE, CULL, STACK, TRIS, SPILL, WL, IO>), dim3(wgs), dim3(LBLOCK), bytes, s, sc, io, count, spill);
+    hipLaunchKernelGGL((k_trace_lds<MODE, CULL, STACK, TRIS, SPILL, WL, IO>), dim3(wgs), dim3(LBLOCK), bytes, s, sc, io, count, spill, g_ticket);
 }
 
 // The persistent grid of the global variant is exactly the workgroups that are resident at once: every workgroup
@@ -814,7 +864,7 @@ void launch_global_q(hipStream_t s, int cus, const DevScene &sc, const IO &io, c
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace_global<MODE, CULL, 16, QUANT, IO>, GBLOCK, 0) != hipSuccess || n < 1) n = 6;
         per_cu = n < GLOBAL_WGS_MAX ? n : GLOBAL_WGS_MAX;
     }
-    hipLaunchKernelGGL((k_trace_global<MODE, CULL, 16, QUANT, IO>), dim3(per_cu * cus), dim3(GBLOCK), 0, s, sc, io, count, spill);
+    hipLaunchKernelGGL((k_trace_global<MODE, CULL, 16, QUANT, IO>), dim3(per_cu * cus), dim3(GBLOCK), 0, s, sc, io, count, spill, g_ticket);
 }
 template <int MODE, bool CULL, class IO>
 void launch_global(hipStream_t s, int cus, const DevScene &sc, const IO &io, const uint32_t *count, uint32_t *spill, bool quant) {
@@ -826,6 +876,7 @@ template <int MODE, bool CULL, class IO>
 void launch(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, const IO &io,
             const uint32_t *count) {
     const int cus = blocks / 8 > 0 ? blocks / 8 : 1;
+    g_ticket = cfg.ticket;
     const size_t stack_bytes = (size_t)cfg.stack_entries * LBLOCK * sizeof(uint32_t);
     if (cfg.variant == PT_VARIANT_LDS_NODES && cfg.wgs_per_cu == 1) {
         // mid-size trees: all wide nodes in LDS next to 16 stack entries per lane (deeper stacks spill), one workgroup per CU
@@ -870,6 +921,8 @@ void pt_launch_shadow(hipStream_t s, int blocks, const TraverseConfig &cfg, cons
     if (cfg.cull) launch<MODE_SHADOW, true>(s, blocks, cfg, sc, io, count);
     else launch<MODE_SHADOW, false>(s, blocks, cfg, sc, io, count);
 }
+
+int pt_dynamic_claim(void) { return PT_DYNAMIC_CLAIM; }
 
 size_t pt_worklist_bytes(void) { return (size_t)(LBLOCK / 64) * WL_WORDS * sizeof(uint32_t); }
 
