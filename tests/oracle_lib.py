@@ -45,7 +45,7 @@ class Oracle:
         """strict: pt_oracle.c built with literal arithmetic; literal: oracle/pt_literal.c, the independent transcription in the
         reference's own shape (it offers the subset of entry points the literal comparisons use)"""
         name = "libpt_literal.so" if literal else "libpt_oracle_strict.so" if strict else "libpt_oracle.so"
-        path = os.path.join(ORACLE_DIR, "build", name)
+        path = os.path.join(os.environ.get("PT_ORACLE_BUILD_DIR") or os.path.join(ORACLE_DIR, "build"), name)   # (a sanitizer build, tools/sanitize/run_oracle.sh)
         if not os.path.exists(path):
             subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
         L = ctypes.CDLL(path)
