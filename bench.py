@@ -234,6 +234,7 @@ def main():
     ap.add_argument("--worklist", type=int, default=None, help="library option worklist (1: off, 2: per-wave work list of triangle tests in the LDS kernels)")
     ap.add_argument("--tails", type=int, default=None, help="library option tails (1: every kernel its own launch, 2: shadow(b) + extend(b+1) in one traversal launch)")
     ap.add_argument("--state", type=int, default=None, help="library option state (1: ray state in place by path id, 2: it follows the queue)")
+    ap.add_argument("--tree-builder", type=int, default=None, help="library option tree_builder (1: host SAH, 2: GPU linear BVH), read at upload")
     ap.add_argument("--pipeline", type=int, default=None, help="library option pipeline (1: off, 2: the next batch's raygen on its own stream)")
     ap.add_argument("--keep-reference-tree", action="store_true",
                     help="walk the BVH exactly as uploaded instead of the hierarchy rebuilt over its leaves")
@@ -295,7 +296,7 @@ def main():
     scene = scenes.make(cfg["scene"])
 
     ctx = native.Context(local_rank)
-    ctx.set_options(keep_reference_tree=int(args.keep_reference_tree))
+    ctx.set_options(keep_reference_tree=int(args.keep_reference_tree), **({"tree_builder": args.tree_builder} if args.tree_builder is not None else {}))
     t_up = time.perf_counter()
     ctx.upload_scene(scene)
     upload_wall_ms = (time.perf_counter() - t_up) * 1e3
@@ -394,7 +395,7 @@ def main():
         # same view), so they apply whatever --steps / --warmup are; any flag that changes the dispatch itself rules them out
         is_profiled = (not overridden and world == 1 and args.traversal == "auto"
                        and not args.perf_mode and args.sort is None and args.overlap is None and not args.keep_reference_tree
-                       and args.frames_per_batch == 0 and args.worklist is None and args.tails is None and args.state is None and args.pipeline is None)
+                       and args.frames_per_batch == 0 and args.worklist is None and args.tails is None and args.state is None and args.pipeline is None and args.tree_builder is None)
         traffic, traffic_src = pmc_traffic(args.config, is_profiled)
 
         def kernel_entry(label, name, ms, launches, units, bytes_per_unit):

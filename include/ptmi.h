@@ -106,7 +106,12 @@ typedef struct ptmi_options {
                                    last bounces of batch k, whose small queues leave the machine half idle. Applies to consecutive batches
                                    of one dispatch and to consecutive asynchronous dispatches alike; same kernels, same order of additions,
                                    same bits. 0 = library default */
-    uint32_t reserved[4];
+    uint32_t tree_builder;      /* read by ptmi_upload_scene: who builds the traversal hierarchy over the uploaded leaves (when
+                                   keep_reference_tree = 0). 1 = the host (full-sweep / binned SAH + rotations, threaded: 137 ms for the
+                                   334 174 leaves of the 1 M-triangle scene); 2 = the GPU (Morton-order linear BVH: radix sort + radix
+                                   tree + bottom-up fit, a few ms) — the same leaves and exact unions, hence the same results; a
+                                   Morton tree tests more boxes per ray (profiles/README.md). 0 = library default (1) */
+    uint32_t reserved[3];
 } ptmi_options;
 
 typedef struct ptmi_stats {

@@ -44,7 +44,7 @@ def test_scene_header_symbols_exported():
 def test_abi_version_and_struct_sizes(lib):
     from ptmi import native
     assert lib.ptmi_abi_version() == native.ABI_VERSION == 3
-    assert ctypes.sizeof(native.Options) == 23 * 4      # ABI 3: worklist, tails, state, pipeline, 4 reserved words
+    assert ctypes.sizeof(native.Options) == 23 * 4      # ABI 3: worklist, tails, state, pipeline, tree_builder, 3 reserved words
     # ptmi_stats: 5 + 64 u64, 2 f64 + u64 + 2 f64, 4 u32; ABI 2 adds 3 u64 + 6 f64
     assert ctypes.sizeof(native.Stats) == (5 + 64) * 8 + 5 * 8 + 16 + 9 * 8 + 16      # ABI 3: worklist_used, tails_used, state_used, pipeline_used
 
@@ -53,7 +53,7 @@ def test_ctypes_structs_match_the_header(tmp_path):
     """sizeof / offsetof of every struct the binding mirrors, as a C compiler lays out include/ptmi.h."""
     from ptmi import native
     src = tmp_path / "sizes.c"
-    fields = {"ptmi_options": ["max_bounces", "timing", "tile_strip", "perf_mode", "ray_sort", "worklist", "tails", "state", "pipeline"],
+    fields = {"ptmi_options": ["max_bounces", "timing", "tile_strip", "perf_mode", "ray_sort", "worklist", "tails", "state", "pipeline", "tree_builder"],
               "ptmi_stats": ["paths", "segments_by_bounce", "gpu_ms", "extend_launches", "bvh_depth", "shadow_traced",
                              "raygen_ms", "upload_copy_ms", "worklist_used", "tails_used", "state_used", "pipeline_used"]}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "ptmi.h"', 'int main(void) {']

@@ -15,6 +15,11 @@ struct PtFastLeaf {
 void pt_build_fast_tree(const std::vector<PtFastLeaf> &leaves, std::vector<float4> &wnodes, uint32_t &root_ref,
                         uint32_t &depth);
 
+// The same kind of hierarchy built on the device `s` belongs to (gpu_tree.hip: Morton-order linear BVH; ptmi_options.tree_builder = 2).
+// Synchronises the stream. false: could not (allocation failure, non-finite centroids, more than 60 levels) — the caller builds on the host.
+bool pt_build_fast_tree_gpu(const std::vector<PtFastLeaf> &leaves, std::vector<float4> &wnodes, uint32_t &root_ref, uint32_t &depth,
+                            hipStream_t s);
+
 // Quantised image of that hierarchy for the global traversal variant (layout: traverse.hip, QuantMem).
 //   qnodes      2 uint4 per wide node: child boxes as 16-bit plane numbers on the grid origin + k * scale, rounded outward
 //               (verified with the same fmaf the kernel evaluates), child references (leaf: PT_REF_LEAF | dword offset into

@@ -269,6 +269,7 @@ struct Built {
     float q_origin[3] = {0, 0, 0}, q_scale[3] = {0, 0, 0};
     uint32_t q_top = 0;                      // quantised nodes numbered breadth-first at the front (LDS-resident in the kernel)
     uint32_t max_leaf_tris = 0;
+    bool gpu_tree = false;                   // the rebuilt hierarchy came from the device (ptmi_options.tree_builder = 2)
 };
 
 uint32_t leaf_ref(const ptmi_bvh_node &n) {
@@ -355,7 +356,12 @@ int build_image(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_
     }
     if (nested && leaves.size() >= 2 && !c->opt.keep_reference_tree) {
         const auto t0 = std::chrono::steady_clock::now();
-        pt_build_fast_tree(leaves, b.fast_wnodes, b.fast_root, b.fast_depth);
+        // tree_builder = 2: on the device (gpu_tree.hip); the host builder when that is not wanted, not possible (ptmi_debug_image_stats
+        // has no device) or refused
+        bool built = false;
+        if (c->opt.tree_builder == 2u && c->stream) built = pt_build_fast_tree_gpu(leaves, b.fast_wnodes, b.fast_root, b.fast_depth, c->stream);
+        b.gpu_tree = built;
+        if (!built) pt_build_fast_tree(leaves, b.fast_wnodes, b.fast_root, b.fast_depth);
         b.tree_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     // triangle images: v0, e1 = v1 - v0, e2 = v2 - v0 (pt.wgsl:128-129; one IEEE subtraction each)
@@ -678,6 +684,7 @@ int ptmi_set_options(ptmi_ctx *c, const ptmi_options *o) {
     if (o->tails > 2) return fail(c, PTMI_E_INVALID, "unknown tails %u", o->tails);
     if (o->state > 2) return fail(c, PTMI_E_INVALID, "unknown state %u", o->state);
     if (o->pipeline > 2) return fail(c, PTMI_E_INVALID, "unknown pipeline %u", o->pipeline);
+    if (o->tree_builder > 2) return fail(c, PTMI_E_INVALID, "unknown tree_builder %u", o->tree_builder);
     c->opt = *o;
     return PTMI_OK;
 }

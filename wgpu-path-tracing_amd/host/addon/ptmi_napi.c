@@ -169,6 +169,7 @@ static void read_options(napi_env env, napi_value obj, ptmi_options *o) {
     o->tails = get_u32_prop(env, obj, "tails", o->tails);
     o->state = get_u32_prop(env, obj, "state", o->state);
     o->pipeline = get_u32_prop(env, obj, "pipeline", o->pipeline);
+    o->tree_builder = get_u32_prop(env, obj, "treeBuilder", o->tree_builder);
 }
 
 static napi_value js_set_options(napi_env env, napi_callback_info info) {

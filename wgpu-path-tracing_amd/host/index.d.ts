@@ -38,6 +38,8 @@ export interface TraceOptions {
   state?: 0 | 1 | 2;
   /** 0 (library default) / 1 off / 2 the next batch's camera rays are generated on their own stream beside this batch's last bounces */
   pipeline?: 0 | 1 | 2;
+  /** read at loadModel: 0 (library default) / 1 the host builds the traversal hierarchy (SAH) / 2 the GPU does (linear BVH) */
+  treeBuilder?: 0 | 1 | 2;
 }
 export interface Stats {
   paths: number; segments: number; shadowRays: number; frames: number; dispatches: number;

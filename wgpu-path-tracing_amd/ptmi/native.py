@@ -46,7 +46,7 @@ class Options(ctypes.Structure):
                 ("tile_parts", ctypes.c_uint32), ("tile_part", ctypes.c_uint32), ("tile_strip", ctypes.c_uint32),
                 ("perf_mode", ctypes.c_uint32), ("ray_sort", ctypes.c_uint32), ("overlap", ctypes.c_uint32),
                 ("worklist", ctypes.c_uint32), ("tails", ctypes.c_uint32), ("state", ctypes.c_uint32),
-                ("pipeline", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 4)]
+                ("pipeline", ctypes.c_uint32), ("tree_builder", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 3)]
 
 
 class Stats(ctypes.Structure):
