@@ -510,18 +510,24 @@ int ptmi_create(int device_ordinal, ptmi_ctx **out) {
     }
     c->stream = c->own_stream;
     {
-        // The shadow stream runs at the main stream's priority. At the lowest priority its waves are held back whenever a
-        // main-stream kernel has work to issue; measured, five interleaved runs each (Msamples/s): config 1 lowest 9 173,
-        // equal 9 244 (run-to-run +-130); config 3 lowest 4 744, equal 4 808 (both rounds). -DPT_SIDE_LOW_PRIORITY restores it.
+        // The shadow stream has a priority level of its own — HIGH — because a priority level has hardware queues of its own. At the
+        // caller's (normal) priority the runtime multiplexes it with every other normal-priority stream of the process onto a few
+        // hardware queues, and what it gets depends on what was created before: the first context of a process is fine, a context made
+        // after another one was destroyed got its shadow stream onto that one's old main queue and ran 6 - 9 % slower, at the
+        // one-stream rate (tools/two_contexts.py b, profiles/r03_queues/). At high or at low priority that case is gone; in the ordinary
+        // case the three are level (config 1: normal 9 966, high 9 970, low 9 939; config 3: 5 027 / 5 037 / 5 031, interleaved;
+        // round 2 had measured low 0.8 - 1.3 % behind normal). -DPT_SIDE_NORMAL_PRIORITY / -DPT_SIDE_LOW_PRIORITY build the others.
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         bool ok = true;
         for (Lane &ln : c->lanes) {
             ok = ok && hipStreamCreateWithFlags(&ln.main, hipStreamNonBlocking) == hipSuccess;
-#ifdef PT_SIDE_LOW_PRIORITY
+#if defined(PT_SIDE_LOW_PRIORITY)
             ok = ok && hipStreamCreateWithPriority(&ln.side, hipStreamNonBlocking, lo) == hipSuccess;
-#else
+#elif defined(PT_SIDE_NORMAL_PRIORITY)
             ok = ok && hipStreamCreateWithFlags(&ln.side, hipStreamNonBlocking) == hipSuccess;
+#else
+            ok = ok && hipStreamCreateWithPriority(&ln.side, hipStreamNonBlocking, hi) == hipSuccess;
 #endif
             // The `pre` stream (ptmi_options.pipeline) is created at the LOWEST priority, for two reasons: its `raygen` is meant to fill
             // idle wave slots, never to take them; and the runtime multiplexes streams of one priority onto a few hardware queues
