@@ -59,6 +59,10 @@ def shadow_bytes_per_ray(l_bytes=12):
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
 PROFILE_TAG = "r03"                     # profiles/<tag>_cfgN_*.json are the counter passes replayed in `roofline`
 
+# kernel names in the counter files (tools/pmc_summary.py): traverse.hip's and traverse_own.hip's; a config runs one per kind
+EXTEND_KEYS = ("k_trace_lds/extend", "k_trace_global/extend", "k_own_lds/extend", "k_own_global/extend")
+SHADOW_KEYS = ("k_trace_lds/shadow", "k_trace_global/shadow", "k_own_lds/shadow", "k_own_global/shadow")
+
 CONFIGS = {
     0: dict(scene="cornell", width=256, height=256, spp=16, fps=16, bounces=4, mis=0, aperture=0.001, focus=5.0,
             scaling="weak", name="configs[0]"),
@@ -128,8 +132,7 @@ def pmc_traffic(config, is_profiled_workload):
         return {}, None
     d = json.load(open(path))
     out = {}
-    for label, keys in (("extend", ("k_trace_lds/extend", "k_trace_global/extend")),
-                        ("shadow", ("k_trace_lds/shadow", "k_trace_global/shadow")), ("shade", ("k_shade",))):
+    for label, keys in (("extend", EXTEND_KEYS), ("shadow", SHADOW_KEYS), ("shade", ("k_shade",))):
         f = w = 0.0
         for k in keys:          # a config uses one variant per kernel; a missing key contributes nothing
             f += d.get("FETCH_SIZE", {}).get(k, {}).get("avg_KB_per_launch", 0.0) * d.get("FETCH_SIZE", {}).get(k, {}).get("launches", 0)
@@ -161,8 +164,7 @@ def valu_issue(config, is_profiled_workload, launches, gpu_ms):
         return None
     d = json.load(open(path)).get("SQ_ACTIVE_INST_VALU", {})
     per = {}
-    for label, keys in (("extend", ("k_trace_lds/extend", "k_trace_global/extend")),
-                        ("shadow", ("k_trace_lds/shadow", "k_trace_global/shadow")), ("shade", ("k_shade",))):
+    for label, keys in (("extend", EXTEND_KEYS), ("shadow", SHADOW_KEYS), ("shade", ("k_shade",))):
         q = sum(d.get(k, {}).get("avg_per_launch", 0.0) for k in keys)
         if q:
             per[label] = q
@@ -171,8 +173,7 @@ def valu_issue(config, is_profiled_workload, launches, gpu_ms):
     # lane utilisation of VALU instructions from the same pass: thread-cycles / (64 x instruction quad-cycles)
     tc = json.load(open(path)).get("SQ_THREAD_CYCLES_VALU", {})
     lane_util = {}
-    for label, keys in (("extend", ("k_trace_lds/extend", "k_trace_global/extend")),
-                        ("shadow", ("k_trace_lds/shadow", "k_trace_global/shadow")), ("shade", ("k_shade",))):
+    for label, keys in (("extend", EXTEND_KEYS), ("shadow", SHADOW_KEYS), ("shade", ("k_shade",))):
         t = sum(tc.get(k, {}).get("avg_per_launch", 0.0) for k in keys)
         if t and per.get(label):
             lane_util[label] = round(t / (64.0 * per[label]), 4)
@@ -203,6 +204,7 @@ def cpu_baseline(scene, cam_kw, width, height, bounces, mis, threads, target_s=1
                        do_mis=mis, out=out, threads=threads)
     return {
         "value": round(st.segments / st.seconds / 1e6, 4), "unit": "Msamples/s", "cores": int(st.threads),
+        "cores_available": int(os.cpu_count() or 0),
         "kind": "port",
         "sample": f"frames 1..{frames} of the full {width}x{height} frame: {st.paths} paths, {st.segments} segments "
                   f"in {st.seconds:.2f} s (oracle/pt_oracle.c contract build, OpenMP dynamic rows)",
@@ -227,15 +229,17 @@ def main():
     ap.add_argument("--traversal", default="auto", choices=["auto", "global", "lds", "global_exact"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--perf-mode", type=int, default=0, help="library option perf_mode (0 = parity arithmetic, the headline)")
-    ap.add_argument("--sort", type=int, default=None, help="library option ray_sort (default: the library's)")
     ap.add_argument("--overlap", type=int, default=None,
-                    help="library option overlap (0: one stream; 1: shadow kernel on a second stream; 3: also two half-batches in "
-                         "flight; default: the library's)")
-    ap.add_argument("--worklist", type=int, default=None, help="library option worklist (1: off, 2: per-wave work list of triangle tests in the LDS kernels)")
-    ap.add_argument("--tails", type=int, default=None, help="library option tails (1: every kernel its own launch, 2: shadow(b) + extend(b+1) in one traversal launch)")
-    ap.add_argument("--state", type=int, default=None, help="library option state (1: ray state in place by path id, 2: it follows the queue)")
+                    help="library option overlap (0: one stream; 1: shadow kernel on a second stream; default: the library's)")
     ap.add_argument("--tree-builder", type=int, default=None, help="library option tree_builder (1: host SAH, 2: GPU linear BVH), read at upload")
-    ap.add_argument("--pipeline", type=int, default=None, help="library option pipeline (1: off, 2: the next batch's raygen on its own stream)")
+    ap.add_argument("--leaves", type=int, default=None,
+                    help="library option leaves, read at upload (1: the uploaded BVH's leaves; 2: the library's own leaves; default: the library's)")
+    ap.add_argument("--leaf-tris", type=int, default=None, help="library option leaf_tris (most triangles per own leaf)")
+    ap.add_argument("--no-leaves-compare", action="store_true",
+                    help="skip the second timed leg (N = 1 only) that renders the same steps with the OTHER leaf mode for `leaves_compare`")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1 from ONE process: ptmi_multi_* (one host thread, one stream per device, the library's own RCCL gather) "
+                         "instead of one rank per GPU under torch.distributed")
     ap.add_argument("--keep-reference-tree", action="store_true",
                     help="walk the BVH exactly as uploaded instead of the hierarchy rebuilt over its leaves")
     ap.add_argument("--rehearse", action="store_true",
@@ -262,9 +266,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.single_process:
+        return single_process(args, cfg, overridden, steps, fps, spp)
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+            # not under a launcher: start one rank per GPU ourselves — fresh child processes, before this one has touched a GPU —
+            # and pass rank 0's JSON line through (the driver's own command is exactly this child command)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            sys.exit(subprocess.call(cmd))
         args.gpus = world
 
     import numpy as np
@@ -296,7 +310,11 @@ def main():
     scene = scenes.make(cfg["scene"])
 
     ctx = native.Context(local_rank)
-    ctx.set_options(keep_reference_tree=int(args.keep_reference_tree), **({"tree_builder": args.tree_builder} if args.tree_builder is not None else {}))
+    upload_opts = {"keep_reference_tree": int(args.keep_reference_tree)}
+    for k, v in (("tree_builder", args.tree_builder), ("leaves", args.leaves), ("leaf_tris", args.leaf_tris)):
+        if v is not None:
+            upload_opts[k] = v
+    ctx.set_options(**upload_opts)
     t_up = time.perf_counter()
     ctx.upload_scene(scene)
     upload_wall_ms = (time.perf_counter() - t_up) * 1e3
@@ -314,18 +332,8 @@ def main():
     extra = {}
     if args.perf_mode:
         extra["perf_mode"] = args.perf_mode
-    if args.sort is not None:
-        extra["ray_sort"] = args.sort
     if args.overlap is not None:
         extra["overlap"] = args.overlap
-    if args.worklist is not None:
-        extra["worklist"] = args.worklist
-    if args.tails is not None:
-        extra["tails"] = args.tails
-    if args.state is not None:
-        extra["state"] = args.state
-    if args.pipeline is not None:
-        extra["pipeline"] = args.pipeline
     ctx.set_options(max_bounces=cfg["bounces"], do_mis=mis, frames_per_batch=args.frames_per_batch, traversal=trav, cull=1,
                     timing=args.timing, **extra, **shard.strip_options(world, rank, strip))
 
@@ -354,6 +362,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_leg = time.perf_counter()
     for _ in range(args.warmup):
         step()
     gather()                                  # also sets up the RCCL channels outside the timed region
@@ -365,8 +374,32 @@ def main():
     gather()
     fence()
     dt = time.perf_counter() - t0
+    leg_seconds = {"gpu_warmup_and_timed": round(time.perf_counter() - t_leg, 3)}
 
     st = ctx.stats()
+    # the same steps with the OTHER leaf mode (N = 1): both numbers stay in the record while the own leaves are new
+    leaves_compare = None
+    if world == 1 and not args.no_leaves_compare and not args.rehearse and not args.keep_reference_tree:
+        t_leg = time.perf_counter()
+        other = 1 if int(st.leaves_used) == 2 else 2
+        ctx.set_options(leaves=other)
+        ctx.upload_scene(scene)
+        frame_index = 0
+        for _ in range(args.warmup):
+            step()
+        fence()
+        ctx.reset_stats()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        dt2 = time.perf_counter() - t1
+        st2 = ctx.stats()
+        leaves_compare = {"leaves": int(st2.leaves_used), "value": round(st2.segments / dt2 / 1e6, 3), "ms_per_step": round(dt2 / steps * 1e3, 3),
+                          "segments": int(st2.segments), "same_segments": bool(int(st2.segments) == int(st.segments)),
+                          "extend_variant": int(st2.extend_variant), "shadow_variant": int(st2.shadow_variant),
+                          "kernel_ms": {"extend": round(st2.extend_ms, 3), "shade": round(st2.shade_ms, 3), "shadow": round(st2.shadow_ms, 3)}}
+        leg_seconds["gpu_leaves_compare"] = round(time.perf_counter() - t_leg, 3)
     rehearsal_ok = None
     if args.rehearse and rank == 0:
         # the same frames, unsharded, on this rank alone: the sharded + gathered frame must equal it bit for bit
@@ -394,8 +427,8 @@ def main():
         # the counter files hold per-launch means of this config's dispatch; every step is such a dispatch (64 more frames of the
         # same view), so they apply whatever --steps / --warmup are; any flag that changes the dispatch itself rules them out
         is_profiled = (not overridden and world == 1 and args.traversal == "auto"
-                       and not args.perf_mode and args.sort is None and args.overlap is None and not args.keep_reference_tree
-                       and args.frames_per_batch == 0 and args.worklist is None and args.tails is None and args.state is None and args.pipeline is None and args.tree_builder is None)
+                       and not args.perf_mode and args.overlap is None and not args.keep_reference_tree
+                       and args.frames_per_batch == 0 and args.tree_builder is None and args.leaves is None and args.leaf_tris is None)
         traffic, traffic_src = pmc_traffic(args.config, is_profiled)
 
         def kernel_entry(label, name, ms, launches, units, bytes_per_unit):
@@ -444,8 +477,11 @@ def main():
                 "traversal": "lds" if st.traversal_used == native.TRAVERSAL_LDS else "global",
                 "triangles": int(len(scene.tris)), "bvh_nodes": int(len(scene.nodes)), "parallelism": par,
                 **({"perf_mode": args.perf_mode} if args.perf_mode else {}),
-                "worklist_used": int(st.worklist_used), "tails_used": int(st.tails_used), "state_used": int(st.state_used), "pipeline_used": int(st.pipeline_used),
+                "leaves": int(st.leaves_used), "leaf_tris": int(st.leaf_tris_used),
+                "extend_variant": int(st.extend_variant), "shadow_variant": int(st.shadow_variant),
             },
+            "verify_failed_rank0": int(st.verify_failed),
+            **({"leaves_compare": leaves_compare} if leaves_compare else {}),
             **({"rehearsal": {"sharded_equals_unsharded_bitwise": rehearsal_ok, "backend": "gloo", "note": "all ranks on one GPU; not a benchmark"}} if args.rehearse else {}),
             "segments": int(segments), "shadow_rays": int(shadow_rays), "paths": int(paths),
             "shadow_traced_rank0": int(st.shadow_traced),
@@ -480,7 +516,11 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, cam_kw, W, H, cfg["bounces"], mis, min(16, os.cpu_count() or 1))
+            t_leg = time.perf_counter()
+            out["cpu_baseline"] = cpu_baseline(scene, cam_kw, W, H, cfg["bounces"], mis, os.cpu_count() or 1)
+            leg_seconds["cpu_baseline"] = round(time.perf_counter() - t_leg, 3)
+        # where the wall time of this command went: the GPU is idle during the CPU-baseline leg (a sampled gpu_busy of 0 % has its reason here)
+        out["leg_seconds"] = leg_seconds
         print(json.dumps(out), flush=True)
 
     ctx.close()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PTMI_ABI_VERSION 3
+#define PTMI_ABI_VERSION 4
 
 enum {
     PTMI_OK = 0,
@@ -72,46 +72,32 @@ typedef struct ptmi_options {
                                    1: `shade` may use the device's fast reciprocal / reciprocal square root / square root
                                    (1 ulp) instead of the correctly rounded forms. Same RNG streams and control flow; radiance
                                    agrees statistically (tests/test_gpu_perf_mode.py), not bit for bit. Never the headline. */
-    uint32_t ray_sort;          /* 0: queues keep ascending path order; 1: within each 1024-slot window of the queue surviving rays
-                                   are grouped by direction octant before the next traversal (coherent waves; results unchanged);
-                                   2 = library default (currently the measured better of the two) */
+    uint32_t reserved_a;        /* must be 0 (ABI <= 3: ray_sort — survivors grouped by direction octant; measured slower and removed,
+                                   profiles/README.md "Removed in round 4") */
     uint32_t overlap;           /* 0: every kernel of a dispatch on the context's one stream, in order; 1: the any-hit `shadow` kernel of
                                    bounce b runs on a second stream beside `extend` / `shade` of bounce b + 1 — it is
                                    the only kernel that adds to the radiance then, in bounce order, so results are unchanged;
-                                   3: additionally each batch is traced as two halves on two lanes (own buffers and streams), the
-                                   second started when the first has finished bounce 3, so that a half's last bounces run beside
-                                   the next half's first ones; the halves are folded into the output in frame order on the
-                                   context's stream (same bits; measured slower than 1, kept for
-                                   experiments). 2 = library default (currently 1) */
-    /* ABI 3 */
-    uint32_t worklist;          /* triangle tests of the LDS traversal kernels through a per-wave work list: lanes list the triangles
-                                   of the leaves they open as (ray lane, triangle) items in LDS and all 64 lanes take one item each,
-                                   the closest hit reduced with an LDS 64-bit minimum on (t bits, triangle) — the same (t, lowest
-                                   index) rule, so results are unchanged. 0 = library default, 1 = off, 2 = on where it fits */
-    uint32_t tails;             /* how the last bounces' small queues (from bounce 4 on, a tenth of the rays) are scheduled when `shadow` has
-                                   its own stream: 0 = library default, 1 = like every other bounce (shadow(b) beside extend / shade of
-                                   bounce b + 1), 2 = on ONE stream, every kernel by itself, shadow(b) behind the compaction of bounce b
-                                   (no second persistent traversal grid holding the CUs' LDS while the next small extend arrives).
-                                   Results unchanged: `shadow` stays the only kernel adding to the radiance, in bounce order */
-    uint32_t state;             /* where a path's ray state (origin + RNG, direction, throughput) lives between bounces: 1 = in place,
-                                   indexed by path id for the whole batch (by bounce 4 the survivors are 7 % of the paths: every read
-                                   fetches a memory sector for 16 bytes of it); 2 = it follows the queue: `shade` of bounce b writes the
-                                   survivors' state at their slot of bounce b's queue into a second set of buffers (+ the path id, for
-                                   the radiance), the next queue lists those slots, so the next bounce reads it at the density of ONE
-                                   bounce's survival rate. Same arithmetic, same results. 0 = library default */
-    uint32_t pipeline;          /* 1 = every batch generates its camera rays on the stream that traces it; 2 = the camera rays of a batch
-                                   are generated on a stream of their own, into a second set of the buffers `raygen` writes (origin /
-                                   direction / radiance, alternating by batch, +48 B per path), as soon as the batch before the previous
-                                   one has been folded — so the write-bound `raygen` of batch k + 1 (1.2 ms per 133 M paths) runs beside the
-                                   last bounces of batch k, whose small queues leave the machine half idle. Applies to consecutive batches
-                                   of one dispatch and to consecutive asynchronous dispatches alike; same kernels, same order of additions,
-                                   same bits. 0 = library default */
+                                   2 = library default (currently 1) */
+    uint32_t reserved_b[4];     /* must be 0 (ABI 3: worklist, tails, state, pipeline — four ways to compute the same bits, each measured
+                                   slower or level and removed in round 4; numbers and the last commit that had them: profiles/README.md) */
     uint32_t tree_builder;      /* read by ptmi_upload_scene: who builds the traversal hierarchy over the uploaded leaves (when
                                    keep_reference_tree = 0). 1 = the host (full-sweep / binned SAH + rotations, threaded: 137 ms for the
                                    334 174 leaves of the 1 M-triangle scene); 2 = the GPU (Morton-order linear BVH: radix sort + radix
                                    tree + bottom-up fit, a few ms) — the same leaves and exact unions, hence the same results; a
                                    Morton tree tests more boxes per ray (profiles/README.md). 0 = library default (1) */
-    uint32_t reserved[3];
+    /* ABI 4 */
+    uint32_t leaves;            /* read by ptmi_upload_scene: which leaves the traversal kernels test triangles in.
+                                   1 = the uploaded BVH's own leaves (bvh.ts:86-127 cuts <= 4 triangles from 11 equal-count candidates on one
+                                       axis): a triangle is tested iff the box of ITS reference leaf passes, exactly as pt.wgsl:248-291 does;
+                                   2 = the library's own leaves: a full-sweep SAH hierarchy over the TRIANGLES (leaf_tris at most per leaf),
+                                       boxes padded outward so that they are conservative for the kernels' fused slab test. A ray then tests
+                                       a quarter of the triangles (Cornell: 9.8 -> 2.4 per closest-hit ray). The closest hit is verified
+                                       against the reference leaf's box before it is reported, and a ray whose winner fails that test — or
+                                       whose direction has a zero / non-finite component, or whose origin lies far outside the scene — is
+                                       traced again over the uploaded tree, so results equal mode 1's;
+                                   0 = library default (2) */
+    uint32_t leaf_tris;         /* leaves = 2: most triangles per own leaf, 1 .. 32; 0 = library default (measured: profiles/README.md) */
+    uint32_t reserved[1];
 } ptmi_options;
 
 typedef struct ptmi_stats {
@@ -139,12 +125,13 @@ typedef struct ptmi_stats {
     double   upload_ms;         /* wall time of the last ptmi_upload_scene, and its parts: validation + traversal image, */
     double   upload_tree_ms;    /* ... the hierarchy rebuilt over the uploaded leaves, */
     double   upload_copy_ms;    /* ... host-to-device copies */
-    /* ABI 3 */
-    uint32_t worklist_used;     /* of the last dispatch / per-stage call: bit 0 the closest-hit kernel, bit 1 the any-hit kernel ran the
-                                   per-wave work list (ptmi_options.worklist) */
-    uint32_t tails_used;        /* ... 1: the last bounces ran on one stream (ptmi_options.tails = 2) */
-    uint32_t state_used;        /* ... 1: ray state in place by path id, 2: it followed the queue (ptmi_options.state) */
-    uint32_t pipeline_used;     /* ... 1 / 2: ptmi_options.pipeline as the last dispatch ran (was reserved) */
+    /* ABI 4 (ABI 3 had worklist_used, tails_used, state_used, pipeline_used here) */
+    uint32_t leaves_used;       /* 1 / 2: ptmi_options.leaves as the uploaded scene's traversal image was built */
+    uint32_t leaf_tris_used;    /* most triangles in a leaf of that image */
+    uint32_t extend_variant, shadow_variant;   /* of the last dispatch: PTMI_VARIANT_* the closest-hit / any-hit kernel ran as */
+    /* leaves = 2: closest hits / occluders whose reference leaf's box did not pass and rays that were therefore traced again over the
+     * uploaded tree (both kernels together), since the last reset */
+    uint64_t verify_failed;
 } ptmi_stats;
 
 /* ---- lifetime ----------------------------------------------------------- */
@@ -281,6 +268,22 @@ int ptmi_debug_occluded(ptmi_ctx *ctx, uint32_t n, const float *o3, const float 
  * inner boxes of the rebuilt hierarchy that are not the exact union of their children's boxes, nodes not reached once. */
 int ptmi_debug_image_stats(const ptmi_triangle *triangles, uint32_t n_triangles,
                            const ptmi_bvh_node *bvh_nodes, uint32_t n_nodes, double out[8]);
+/* Host-only (no context, no device): builds the traversal image ptmi_upload_scene would build under opt's `leaves`, `leaf_tris` and
+ * `keep_reference_tree` (NULL: the defaults) and copies it out, for tests and tools that walk it on the CPU. Every buffer may be NULL
+ * (call once for the sizes). wnodes16: n_wnodes x 16 floats (csrc/pt_device.h: two child boxes, two references); qnodes8: n_wnodes x 8
+ * words (only when info->quantised; numbered top-of-tree first, not like wnodes16); tripos12: n_tris x 12 floats — (v0, w), e1, e2 with
+ * w = bits(original triangle index) and the triangles in LEAF order when leaves_used = 2; leafbox8: n_triangles x 8 floats, the box of
+ * the reference leaf that lists each (original) triangle (leaves_used = 2 only). */
+typedef struct ptmi_image_info {
+    uint32_t leaves_used, n_wnodes, n_tris, root_ref, depth, n_leaves, max_leaf_tris, quantised;
+    float root_min[3], root_max[3];   /* the box tested first (leaves_used = 2: padded) */
+    float pad, safe_origin;           /* leaves_used = 2: what every box was padded by; the origin distance the padding is good for */
+    float q_origin[3], q_scale[3];
+    uint32_t ref_depth;               /* levels of the uploaded tree */
+} ptmi_image_info;
+int ptmi_debug_build_image(const ptmi_triangle *triangles, uint32_t n_triangles, const ptmi_bvh_node *bvh_nodes, uint32_t n_nodes,
+                           const ptmi_options *opt, ptmi_image_info *info, float *wnodes16, uint32_t *qnodes8, float *tripos12,
+                           float *leafbox8);
 /* arithmetic-contract probe: out[i] = op(a[i], b[i], c[i]) evaluated on the device.
  * ops: 0 a/b, 1 sqrt(a), 2 fma(a,b,c), 3 min(a,b), 4 max(a,b), 5 sin(a), 6 cos(a),
  *      7 pow5(a), 8 f32(u32 bits of a), 9 u32(a) as bits, 10 a - trunc(a), 11 tan(a), 12 1/a (the kernels' short form) */

@@ -227,9 +227,12 @@ typedef struct {                                                 /* pt.wgsl:86-1
     v3 albedo; float alpha, roughness, metallic, transmission, ior;
     v3 emission; float emissive_strength; float uvx, uvy; int is_front;
 } hitinfo_t;
+/* ray tap (pto_render_tap): every traversal of a render, with its result, for tools that replay real rays elsewhere */
+typedef struct { float *rec; uint64_t cap; uint64_t *n; uint64_t last; } ray_tap_t;
 typedef struct {
     uint64_t segments, shadow_rays, nodes_visited, tris_tested, closest_hits;
     uint32_t max_stack;
+    ray_tap_t *tap;
 } counters_t;
 
 /* ------------------------------------------------------------------------- */
@@ -333,7 +336,21 @@ static hit_t traverse(const pto_scene *s, ray_t r, counters_t *c) {
             if (sp > c->max_stack) c->max_stack = sp;
         }
     }
+    if (c->tap) {                                    /* 9 words per ray: o, d, dist (0: a closest-hit ray), t, tri */
+        ray_tap_t *tp = c->tap;
+        uint64_t i = __atomic_fetch_add(tp->n, 1, __ATOMIC_RELAXED);
+        tp->last = i;
+        if (i < tp->cap) {
+            float *q = tp->rec + 9 * i;
+            q[0] = r.o.x; q[1] = r.o.y; q[2] = r.o.z; q[3] = r.d.x; q[4] = r.d.y; q[5] = r.d.z; q[6] = 0.0f;
+            q[7] = best.t; memcpy(&q[8], &best.tri, 4);
+        }
+    }
     return best;
+}
+/* the ray just traced was a shadow ray: dist < 0 directional (pt.wgsl:392), else the distance of :421 / :463 */
+static void tap_shadow(counters_t *c, float dist) {
+    if (c->tap && c->tap->last < c->tap->cap) c->tap->rec[9 * c->tap->last + 6] = dist;
 }
 
 /* rayTriangleIntersect, pt.wgsl:159-226, for the winning triangle only */
@@ -539,6 +556,7 @@ static light_sample_t sample_light(const pto_scene *s, uint32_t *rng, v3 hit_pos
         ray_t sr = { madd3(wi, PT_EPS, hit_pos), wi };
         c->shadow_rays++;
         hit_t sh = traverse(s, sr, c);
+        tap_shadow(c, -1.0f);
         if (sh.t > 0.0f) { ls.wi = wi; ls.pdf = 0.0f; return ls; }
         ls.intensity = scale3(ld3(lt->color), lt->intensity);
         ls.wi = wi;
@@ -551,6 +569,7 @@ static light_sample_t sample_light(const pto_scene *s, uint32_t *rng, v3 hit_pos
         ray_t sr = { madd3(wi, PT_EPS, hit_pos), wi };
         c->shadow_rays++;
         hit_t sh = traverse(s, sr, c);
+        tap_shadow(c, dist);
         if (sh.t > 0.0f && sh.t < dist - PT_EPS * 2.0f) { ls.wi = wi; ls.pdf = 0.0f; return ls; }
         float att = 1.0f / (dist * dist);
         ls.intensity = scale3(scale3(ld3(lt->color), lt->intensity), att);
@@ -572,6 +591,7 @@ static light_sample_t sample_light(const pto_scene *s, uint32_t *rng, v3 hit_pos
         ray_t sr = { madd3(wi, PT_EPS, hit_pos), wi };
         c->shadow_rays++;
         hit_t sh = traverse(s, sr, c);
+        tap_shadow(c, dist);
         if (sh.t > 0.0f && sh.t < dist - PT_EPS * 2.0f) { ls.wi = wi; ls.pdf = 0.0f; return ls; }
         v3 e1 = sub3(ld3(T->v1), ld3(T->v0)), e2 = sub3(ld3(T->v2), ld3(T->v0));
         float area = length3(cross3(e1, e2)) * 0.5f;
@@ -799,6 +819,39 @@ int pto_render(const pto_scene *s, const ptmi_camera *cam, uint32_t n_frames,
         st->threads = (uint32_t)nthreads;
     }
     return 0;
+}
+
+/* Every ray a render traces, with the traversal's result: rec9[9 i ..] = o.xyz, d.xyz, dist (0: closest-hit ray; < 0: shadow ray to
+ * a directional light; > 0: shadow ray, the light's distance), t (-1: miss), tri (bits). Rows [y0, y1) x n_frames; at most max_rays
+ * are stored (in no particular order); returns how many were traced. No image is written. */
+uint64_t pto_render_tap(const pto_scene *s, const ptmi_camera *cam, uint32_t n_frames, const pto_options *opt,
+                        float *rec9, uint64_t max_rays) {
+    uint32_t W = cam->width, H = cam->height;
+    uint32_t y0 = opt ? opt->y0 : 0u, y1 = (opt && opt->y1) ? opt->y1 : H;
+    uint32_t maxb = opt ? opt->max_bounces : 8u;
+    int do_mis = opt ? (int)opt->do_mis : 1;
+    if (y1 > H) y1 = H;
+    if (y0 > y1) return 0;
+    int nthreads = 1;
+#ifdef _OPENMP
+    nthreads = (opt && opt->threads) ? (int)opt->threads : omp_get_max_threads();
+#endif
+    uint64_t n = 0;
+#pragma omp parallel num_threads(nthreads)
+    {
+        ray_tap_t tap = { rec9, max_rays, &n, 0 };
+        counters_t c; memset(&c, 0, sizeof c);
+        c.tap = &tap;
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t y = y0; y < (int64_t)y1; y++)
+            for (uint32_t x = 0; x < W; x++)
+                for (uint32_t k = 0; k < n_frames; k++) {
+                    uint32_t rng;
+                    ray_t r = camera_ray(cam, x, (uint32_t)y, cam->frame_index + k, &rng);
+                    (void)trace(s, &rng, r, maxb, do_mis, &c, NULL, NULL);
+                }
+    }
+    return n;
 }
 
 int pto_trace_path(const pto_scene *s, const ptmi_camera *cam, uint32_t x, uint32_t y,

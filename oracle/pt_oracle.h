@@ -91,6 +91,13 @@ int pto_occluded(const pto_scene *s, uint32_t n, const float *o3, const float *d
 int pto_render(const pto_scene *s, const ptmi_camera *cam, uint32_t n_frames,
                const pto_options *opt, float *out_rgba, pto_stats *st);
 
+/* Every ray a render traces, with the traversal's result (for tools that replay real rays through another traversal):
+ * rec9[9 i ..] = o.xyz, d.xyz, dist (0: closest-hit ray; < 0: shadow ray to a directional light; > 0: shadow ray, the light's
+ * distance), t (-1: miss), tri (bits). Rows [opt->y0, opt->y1) x n_frames; at most max_rays are stored, in no particular order;
+ * returns how many were traced. No image is written. */
+uint64_t pto_render_tap(const pto_scene *s, const ptmi_camera *cam, uint32_t n_frames, const pto_options *opt,
+                        float *rec9, uint64_t max_rays);
+
 /* One path, with a per-bounce log for debugging parity failures.
  * log: max_bounces+1 records of 16 floats:
  *   [0..2] ray origin, [3..5] ray dir, [6..8] throughput, [9..11] radiance,

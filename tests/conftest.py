@@ -60,5 +60,9 @@ def gpu_ctx():
     """One HIP context for the whole GPU test session (fails loudly when there is no GPU)."""
     from ptmi import native
     ctx = native.Context(0)
+    # PTMI_TEST_LEAVES=1 runs the whole GPU suite over the reference's leaves (ptmi_options.leaves; the default, 2, is the library's
+    # own): tests change options through get -> modify -> set, so the mode stays unless a test names it
+    if os.environ.get("PTMI_TEST_LEAVES"):
+        ctx.set_options(leaves=int(os.environ["PTMI_TEST_LEAVES"]))
     yield ctx
     ctx.close()

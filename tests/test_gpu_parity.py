@@ -291,35 +291,11 @@ def test_tile_rows_and_traversal_modes(gpu_ctx, oracle, scene_factory):
     gpu_ctx.set_options(traversal=native.TRAVERSAL_AUTO, cull=1, tile_y0=0, tile_y1=0)
 
 
-@pytest.mark.parametrize("name", ["cornell", "cornell_spheres"])
-def test_ray_sort_is_invisible(gpu_ctx, oracle, scene_factory, name):
-    """ray_sort = 1 regroups each 1024-slot window of the queue by direction octant before the next traversal: other
-    waves, same rays — the image and the counters must not move by a bit. 200x130 pixels x 5 frames = 130 000 paths:
-    127 windows with a ragged last one, tiles that end inside a window."""
-    sc = scene_factory(name)
-    W, H, frames = 200, 130, 5
-    cam = layout.make_camera(W, H)
-    ref, ost = oracle.render(sc, cam, frames, max_bounces=8, do_mis=1)
-    gpu_ctx.upload_scene(sc)
-    for sort, fpb in ((1, 0), (1, 2), (0, 0)):
-        gpu_ctx.resize(W, H)
-        gpu_ctx.set_options(max_bounces=8, do_mis=1, tile_y0=0, tile_y1=0, tile_parts=0, frames_per_batch=fpb, cull=1, traversal=0,
-                            ray_sort=sort)
-        gpu_ctx.reset_stats()
-        gpu_ctx.dispatch(cam, frames)
-        got = gpu_ctx.read_output()
-        st = gpu_ctx.stats()
-        assert (st.segments, st.shadow_rays, st.paths) == (ost.segments, ost.shadow_rays, ost.paths)
-        assert_same_floats(got, ref, f"radiance (ray_sort {sort}, frames_per_batch {fpb})")
-    gpu_ctx.set_options(ray_sort=2, frames_per_batch=0)
-
-
 @pytest.mark.parametrize("name,trav", [("cornell", 0), ("feature_box", 0), ("cornell_spheres", 1)])
 def test_overlapped_shadow_stream_is_invisible(gpu_ctx, oracle, scene_factory, name, trav):
     """options.overlap: with 1 the shadow kernel of bounce b runs on a second stream beside the next bounce, emissive hits
-    reach the radiance through records, and the record buffers alternate; with 3 every batch is additionally traced as two
-    halves on two lanes, staggered by four bounces and folded in frame order; without it everything is on one stream and
-    `shade` adds emission itself. All must give the oracle's bits and counters — also over several batches in one
+    reach the radiance through records, and the record buffers alternate; without it everything is on one stream and
+    `shade` adds emission itself. Both must give the oracle's bits and counters — also over several batches in one
     dispatch (frames_per_batch 2 of 5 frames: the buffers and events are reused), 1 and 2 bounces (fewer bounces than
     buffers) and with the global traversal variant (its own spill area on the side stream)."""
     sc = scene_factory(name)
@@ -328,7 +304,7 @@ def test_overlapped_shadow_stream_is_invisible(gpu_ctx, oracle, scene_factory, n
     gpu_ctx.upload_scene(sc)
     for bounces in (8, 2, 1):
         ref, ost = oracle.render(sc, cam, frames, max_bounces=bounces, do_mis=1)
-        for overlap, fpb in ((3, 0), (3, 2), (3, 5), (1, 0), (1, 2), (0, 0)):      # 3: two half-batches in flight on two lanes
+        for overlap, fpb in ((1, 0), (1, 2), (1, 5), (0, 0), (0, 2)):
             gpu_ctx.resize(W, H)
             gpu_ctx.set_options(max_bounces=bounces, do_mis=1, tile_y0=0, tile_y1=0, tile_parts=0, frames_per_batch=fpb, cull=1,
                                 traversal=trav, overlap=overlap, timing=3)
@@ -341,17 +317,16 @@ def test_overlapped_shadow_stream_is_invisible(gpu_ctx, oracle, scene_factory, n
     gpu_ctx.set_options(overlap=2, frames_per_batch=0, traversal=0, max_bounces=8, timing=0)
 
 
-def test_two_lanes_across_dispatches(gpu_ctx, oracle, scene_factory):
-    """Consecutive dispatches without a synchronisation in between (the preview loop, the benchmark's steps): with two
-    lanes the second dispatch starts while the first one's last bounces still run, and a lane is reused as soon as its
-    half has been folded. Six dispatches of 4, 1, 3, 2, 6, 1 frames (one-frame dispatches use a single lane: the library
-    drains when the lane layout changes) must leave the oracle's 17 frames."""
+def test_consecutive_dispatches_without_a_synchronisation(gpu_ctx, oracle, scene_factory):
+    """Consecutive dispatches without a synchronisation in between (the preview loop, the benchmark's steps): the shadow stream of
+    one dispatch is still running when the next one is enqueued, and the record buffers and events are reused. Six dispatches of
+    4, 1, 3, 2, 6, 1 frames must leave the oracle's 17 frames."""
     sc = scene_factory("cornell")
     W, H = 128, 96
     ref, ost = oracle.render(sc, layout.make_camera(W, H), 17, max_bounces=8, do_mis=1)
     gpu_ctx.upload_scene(sc)
     gpu_ctx.resize(W, H)
-    gpu_ctx.set_options(max_bounces=8, do_mis=1, tile_y0=0, tile_y1=0, tile_parts=0, frames_per_batch=0, cull=1, traversal=0, overlap=3)
+    gpu_ctx.set_options(max_bounces=8, do_mis=1, tile_y0=0, tile_y1=0, tile_parts=0, frames_per_batch=0, cull=1, traversal=0, overlap=1)
     gpu_ctx.reset_stats()
     k = 0
     for n in (4, 1, 3, 2, 6, 1):
@@ -360,7 +335,7 @@ def test_two_lanes_across_dispatches(gpu_ctx, oracle, scene_factory):
     got = gpu_ctx.read_output()
     st = gpu_ctx.stats()
     assert (st.segments, st.shadow_rays, st.paths) == (ost.segments, ost.shadow_rays, ost.paths)
-    assert_same_floats(got, ref, "radiance after six pipelined dispatches")
+    assert_same_floats(got, ref, "radiance after six unsynchronised dispatches")
     gpu_ctx.set_options(overlap=2)
 
 

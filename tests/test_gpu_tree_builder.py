@@ -15,9 +15,10 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture()
 def tb_ctx(gpu_ctx):
     from ptmi import native
-    gpu_ctx.set_options(tree_builder=2, keep_reference_tree=0)
+    before = gpu_ctx.options().leaves
+    gpu_ctx.set_options(tree_builder=2, keep_reference_tree=0, leaves=1)        # the builder of the hierarchy over the REFERENCE's leaves
     yield gpu_ctx
-    gpu_ctx.set_options(tree_builder=0, traversal=native.TRAVERSAL_AUTO, cull=1, keep_reference_tree=0, overlap=2, frames_per_batch=0,
+    gpu_ctx.set_options(leaves=before, tree_builder=0, traversal=native.TRAVERSAL_AUTO, cull=1, keep_reference_tree=0, overlap=2, frames_per_batch=0,
                         max_bounces=8, do_mis=1)
 
 

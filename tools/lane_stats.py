@@ -16,9 +16,10 @@ name = {1: "cornell", 2: "cornell_spheres", 3: "grid_1m", 4: "cornell"}[cfg]
 W, H, frames = 1920, 1080, 16
 sc = scenes.make(name)
 ctx = native.Context(0)
+ctx.set_options(max_bounces=8, do_mis=1, **json.loads(os.environ.get("PTMI_OPTS", "{}")))      # (before the upload: `leaves` is read there)
 ctx.upload_scene(sc)
 ctx.resize(W, H)
-ctx.set_options(max_bounces=8, do_mis=1, **json.loads(os.environ.get("PTMI_OPTS", "{}")))      # e.g. PTMI_OPTS='{"worklist": 2, "traversal": 2}'
+# e.g. PTMI_OPTS='{"leaves": 1, "traversal": 2}'
 lib = ctypes.CDLL(os.environ["PTMI_LIB"])
 out = (ctypes.c_ulonglong * 32)()
 ctx.dispatch(layout.make_camera(W, H), frames)
@@ -40,4 +41,5 @@ for k, kind in enumerate(("extend", "shadow")):
         "triangles_per_ray": round(tlanes / rays, 3), "triangle_lane_util": round(tlanes / max(titer, 1) / 64, 4),
         "wave_steps_per_64_rays": {"box": round(64 * nsteps / rays, 2), "leaf": round(64 * lsteps / rays, 2), "tri": round(64 * titer / rays, 2)},
     }
-print(json.dumps({"config": cfg, "scene": name, "frames": frames, **res}, indent=1))
+print(json.dumps({"config": cfg, "scene": name, "frames": frames, "leaves": int(st.leaves_used), "extend_variant": int(st.extend_variant),
+                  "shadow_variant": int(st.shadow_variant), "retraced": int(st.verify_failed), **res}, indent=1))

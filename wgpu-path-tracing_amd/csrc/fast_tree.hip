@@ -50,6 +50,7 @@ struct Builder {
     std::vector<float4> &out;             // pre-sized: a tree over n leaves has n - 1 internal nodes
     std::atomic<uint32_t> depth{0};
     std::atomic<int> spare_threads{0};    // how many more subtree tasks may run beside their parent
+    uint32_t depth_limit = 60;            // levels of internal nodes + leaves the tree may have (the traversal stacks' budget)
 
     Box range_box(uint32_t s, uint32_t e) const {
         Box b; b.reset();
@@ -63,7 +64,7 @@ struct Builder {
         double best_cost = INFINITY; int best_axis = -1; uint32_t best_pos = s + n / 2;
         // keep the tree within the traversal stack: near the depth limit fall back to halving
         uint32_t lg = 0; while ((1u << lg) < n) lg++;
-        if (d + lg >= 60) return s + n / 2;
+        if (d + lg >= depth_limit) return s + n / 2;
         if (n <= 4096) {
             // full sweep on every axis
             std::vector<uint32_t> order(n);
@@ -269,10 +270,14 @@ double summed_area(const WideView &v, uint32_t n) {          // SAH proxy: sum o
 #define PT_TREE_ROTATION_DEPTH 0     /* 0 = the rule below; otherwise a fixed depth budget (experiments) */
 #endif
 
-void pt_build_fast_tree(const std::vector<PtFastLeaf> &leaves, std::vector<float4> &wnodes, uint32_t &root_ref,
-                        uint32_t &depth) {
+namespace {
+
+// the greedy top-down build (no rotations): n - 1 wide nodes in preorder over n leaves
+void build_hierarchy(const std::vector<PtFastLeaf> &leaves, std::vector<float4> &wnodes, uint32_t &root_ref, uint32_t &depth,
+                     uint32_t depth_limit) {
     wnodes.clear();
     Builder b{leaves, {}, {}, wnodes};
+    b.depth_limit = depth_limit;
     const uint32_t n = (uint32_t)leaves.size();
     const unsigned hw = std::thread::hardware_concurrency();
     b.spare_threads = (int)std::min(15u, hw > 1 ? hw - 1 : 0u);
@@ -286,27 +291,204 @@ void pt_build_fast_tree(const std::vector<PtFastLeaf> &leaves, std::vector<float
     Box root;
     root_ref = b.build(0, n, 1, 0, root);
     depth = b.depth.load();
-    if (PT_TREE_ROTATIONS > 0 && n > 2 && n <= 65536u && !(root_ref & PT_REF_LEAF)) {     // (334 174 leaves: -1 % area for +0.2 s)
-        const std::vector<float4> before = wnodes;
-        WideView v{wnodes};
-        const bool dbg = std::getenv("PTMI_TREE_DEBUG") != nullptr;
-        const double a0 = dbg ? summed_area(v, root_ref) : 0.0;
-        // Depth budget: the LDS kernels hold a whole node stack per lane (trees of up to 14 levels run two workgroups per
-        // CU), so a small tree may not grow past 14 levels; deeper ones (spilling stacks) get four more levels.
-        const uint32_t max_depth = PT_TREE_ROTATION_DEPTH ? PT_TREE_ROTATION_DEPTH : (depth <= 14u ? 14u : std::min(60u, depth + 4u));
-        size_t total = 0;
-        for (int pass = 0; pass < PT_TREE_ROTATIONS; pass++) {
-            size_t made = 0;
-            rotate_pass(v, root_ref, 1u, max_depth, made);
-            total += made;
-            if (made == 0) break;
-        }
-        const uint32_t d = depth_of(v, root_ref);
-        if (dbg) std::fprintf(stderr, "fast tree: %u leaves, %zu rotations, summed box area %.6g -> %.6g (%.1f %%), depth %u -> %u\n",
-                              n, total, a0, summed_area(v, root_ref), 100.0 * (summed_area(v, root_ref) / a0 - 1.0), depth, d);
-        if (d > 60) wnodes = before;                 // keep within the traversal's depth limit
-        else depth = d;
+}
+
+// bottom-up rotation passes over a finished tree of n_leaves leaves (any leaf references); depth is updated
+void rotate_tree(std::vector<float4> &wnodes, uint32_t root_ref, uint32_t n_leaves, uint32_t &depth, uint32_t depth_cap) {
+    if (!(PT_TREE_ROTATIONS > 0 && n_leaves > 2 && n_leaves <= 65536u && !(root_ref & PT_REF_LEAF))) return;     // (334 174 leaves: -1 % area for +0.2 s)
+    const std::vector<float4> before = wnodes;
+    WideView v{wnodes};
+    const bool dbg = std::getenv("PTMI_TREE_DEBUG") != nullptr;
+    const double a0 = dbg ? summed_area(v, root_ref) : 0.0;
+    // Depth budget: the LDS kernels hold a whole node stack per lane (trees of up to 14 levels run two workgroups per
+    // CU), so a small tree may not grow past 14 levels; deeper ones (spilling stacks) get four more levels.
+    const uint32_t max_depth = PT_TREE_ROTATION_DEPTH ? PT_TREE_ROTATION_DEPTH : (depth <= 14u ? 14u : std::min(depth_cap, depth + 4u));
+    size_t total = 0;
+    for (int pass = 0; pass < PT_TREE_ROTATIONS; pass++) {
+        size_t made = 0;
+        rotate_pass(v, root_ref, 1u, max_depth, made);
+        total += made;
+        if (made == 0) break;
     }
+    const uint32_t d = depth_of(v, root_ref);
+    if (dbg) std::fprintf(stderr, "fast tree: %u leaves, %zu rotations, summed box area %.6g -> %.6g (%.1f %%), depth %u -> %u\n",
+                          n_leaves, total, a0, summed_area(v, root_ref), 100.0 * (summed_area(v, root_ref) / a0 - 1.0), depth, d);
+    if (d > depth_cap) wnodes = before;                 // keep within the traversal's depth limit
+    else depth = d;
+}
+
+}  // namespace
+
+void pt_build_fast_tree(const std::vector<PtFastLeaf> &leaves, std::vector<float4> &wnodes, uint32_t &root_ref,
+                        uint32_t &depth) {
+    build_hierarchy(leaves, wnodes, root_ref, depth, 60u);
+    rotate_tree(wnodes, root_ref, (uint32_t)leaves.size(), depth, 60u);
+}
+
+// ---- own leaves -----------------------------------------------------------------------------------------------------
+#ifndef PT_OWN_C_BOX
+#define PT_OWN_C_BOX 1.0             /* cost of a box-pair step (the unit) */
+#endif
+#ifndef PT_OWN_C_TRI
+#define PT_OWN_C_TRI 0.9             /* ... of one triangle test (54 against ~60 vector instructions) */
+#endif
+#ifndef PT_OWN_C_OPEN
+#define PT_OWN_C_OPEN 0.35           /* ... of opening a leaf (its entry leaves the lane's list, the loop is set up, a share of a vote) */
+#endif
+#ifndef PT_OWN_PAD_LOG2
+#define PT_OWN_PAD_LOG2 (-16)        /* boxes grow by 2^this x the largest coordinate magnitude of the scene */
+#endif
+
+namespace {
+
+double env_or(const char *name, double dflt) {          // experiments only (tools/own_leaf_gate.py)
+    const char *e = std::getenv(name);
+    return e ? std::atof(e) : dflt;
+}
+
+struct Collapse {
+    const std::vector<float4> &w;          // the per-triangle hierarchy
+    uint32_t max_leaf;
+    double c_box, c_tri, c_open;
+    std::vector<uint8_t> leaf;             // internal node -> becomes a leaf
+    std::vector<uint32_t> count;           // triangles below an internal node
+    struct Sub { uint32_t n; double cost; };
+    Sub visit(uint32_t ref, uint32_t level) {
+        if (ref & PT_REF_LEAF) return {1u, c_open + c_tri};
+        WideView v{const_cast<std::vector<float4> &>(w)};
+        const Box bl = v.box(ref, 0), br = v.box(ref, 1);
+        Box all = bl; all.grow(br);
+        const Sub l = visit(v.ref(ref, 0), level + 1), r = visit(v.ref(ref, 1), level + 1);
+        const double a = all.area();
+        const double inner = c_box + (a > 0.0 ? (bl.area() * l.cost + br.area() * r.cost) / a : l.cost + r.cost);
+        const uint32_t n = l.n + r.n;
+        const double as_leaf = c_open + c_tri * n;
+        count[ref] = n;
+        if (n <= max_leaf && as_leaf <= inner) { leaf[ref] = 1; return {n, as_leaf}; }
+        return {n, inner};
+    }
+};
+
+}  // namespace
+
+bool pt_build_own_tree(const ptmi_triangle *tris, const std::vector<uint32_t> &which, uint32_t max_leaf, uint32_t depth_limit,
+                       PtOwnTree &out) {
+    out = PtOwnTree();
+    const uint32_t n = (uint32_t)which.size();
+    if (n == 0) return false;
+    max_leaf = std::max(1u, std::min(max_leaf, PT_LEAF_MAX_TRIS));
+    // one "leaf" per triangle: the box of its three vertices and of v0 + e1, v0 + e2 as the intersection test sees them
+    std::vector<PtFastLeaf> units(n);
+    double biggest = 0.0;
+    for (uint32_t i = 0; i < n; i++) {
+        const ptmi_triangle &t = tris[which[i]];
+        PtFastLeaf &u = units[i];
+        for (int k = 0; k < 3; k++) {
+            const float a = t.v0[k], b = t.v1[k], c = t.v2[k];
+            const float b2 = a + (b - a), c2 = a + (c - a);
+            if (!std::isfinite(a) || !std::isfinite(b) || !std::isfinite(c) || !std::isfinite(b2) || !std::isfinite(c2)) return false;
+            u.mn[k] = std::min(std::min(std::min(a, b), std::min(c, b2)), c2);
+            u.mx[k] = std::max(std::max(std::max(a, b), std::max(c, b2)), c2);
+            biggest = std::max(biggest, std::max(std::fabs((double)u.mn[k]), std::fabs((double)u.mx[k])));
+        }
+        u.ref = PT_REF_LEAF | i; u.weight = 1u;
+    }
+    std::vector<float4> per_tri;
+    uint32_t root = PT_REF_NONE, depth = 0;
+    build_hierarchy(units, per_tri, root, depth, depth_limit);
+    // collapse subtrees into leaves where that is cheaper
+    Collapse col{per_tri, max_leaf, env_or("PTMI_OWN_C_BOX", PT_OWN_C_BOX), env_or("PTMI_OWN_C_TRI", PT_OWN_C_TRI),
+                 env_or("PTMI_OWN_C_OPEN", PT_OWN_C_OPEN), {}, {}};
+    col.leaf.assign(n > 1 ? n - 1 : 0, 0); col.count.assign(n > 1 ? n - 1 : 0, 0);
+    col.visit(root, 1);
+    // emit: surviving internal nodes in preorder, the triangles in the order their leaves hang off them
+    out.tripos.reserve((size_t)n * 3);
+    WideView v{per_tri};
+    auto put_tri = [&](uint32_t unit) {
+        const uint32_t orig = which[unit];
+        const ptmi_triangle &t = tris[orig];
+        float w; std::memcpy(&w, &orig, 4);
+        out.tripos.push_back(make_float4(t.v0[0], t.v0[1], t.v0[2], w));
+        out.tripos.push_back(make_float4(t.v1[0] - t.v0[0], t.v1[1] - t.v0[1], t.v1[2] - t.v0[2], 0.0f));
+        out.tripos.push_back(make_float4(t.v2[0] - t.v0[0], t.v2[1] - t.v0[1], t.v2[2] - t.v0[2], 0.0f));
+    };
+    std::vector<uint32_t> todo;                     // triangles of a subtree, left first
+    auto leaf_of = [&](uint32_t ref) -> uint32_t {
+        const uint32_t first = (uint32_t)(out.tripos.size() / 3);
+        uint32_t cnt = 0;
+        todo.clear(); todo.push_back(ref);
+        while (!todo.empty()) {
+            const uint32_t r = todo.back(); todo.pop_back();
+            if (r & PT_REF_LEAF) { put_tri(r & PT_LEAF_OFF_MASK); cnt++; }
+            else { todo.push_back(v.ref(r, 1)); todo.push_back(v.ref(r, 0)); }
+        }
+        out.n_leaves++; out.max_leaf_tris = std::max(out.max_leaf_tris, cnt);
+        return PT_REF_LEAF | ((cnt - 1u) << PT_LEAF_OFF_BITS) | first;
+    };
+    auto is_leaf = [&](uint32_t ref) { return (ref & PT_REF_LEAF) || col.leaf[ref]; };
+    if (is_leaf(root)) {
+        out.root_ref = leaf_of(root);
+        out.depth = 1;
+    } else {
+        // preorder numbers first (a node's number is known before its subtree is emitted), then one pass that fills them
+        struct Item { uint32_t old_node, new_node; };
+        std::vector<uint32_t> new_of(per_tri.size() / 4, PT_REF_NONE);
+        {
+            std::vector<uint32_t> st{root};
+            uint32_t next = 0;
+            while (!st.empty()) {
+                const uint32_t r = st.back(); st.pop_back();
+                new_of[r] = next++;
+                const uint32_t a = v.ref(r, 0), b = v.ref(r, 1);
+                if (!is_leaf(b)) st.push_back(b);
+                if (!is_leaf(a)) st.push_back(a);
+            }
+            out.wnodes.assign((size_t)next * 4, make_float4(0, 0, 0, 0));
+        }
+        std::vector<uint32_t> st{root};
+        while (!st.empty()) {                        // the same preorder: leaves are numbered in the order a left-first walk meets them
+            const uint32_t r = st.back(); st.pop_back();
+            float4 *w = &out.wnodes[(size_t)new_of[r] * 4];
+            const float4 *q = &per_tri[(size_t)r * 4];
+            w[0] = q[0]; w[1] = q[1]; w[2] = q[2];
+            uint32_t refs[2];
+            for (int side = 0; side < 2; side++) {
+                const uint32_t c = v.ref(r, side);
+                refs[side] = is_leaf(c) ? leaf_of(c) : new_of[c];
+            }
+            float fl, fr; std::memcpy(&fl, &refs[0], 4); std::memcpy(&fr, &refs[1], 4);
+            w[3] = make_float4(fl, fr, 0.0f, 0.0f);
+            const uint32_t a = v.ref(r, 0), b = v.ref(r, 1);
+            if (!is_leaf(b)) st.push_back(b);
+            if (!is_leaf(a)) st.push_back(a);
+        }
+        out.root_ref = 0u;
+        WideView nv{out.wnodes};
+        out.depth = depth_of(nv, 0u);
+        rotate_tree(out.wnodes, out.root_ref, out.n_leaves, out.depth, depth_limit);
+    }
+    // padding (see the header): every child box, and the root box the kernels test first
+    const float pad = std::max((float)std::ldexp(biggest, PT_OWN_PAD_LOG2 + (int)env_or("PTMI_OWN_PAD_EXTRA_LOG2", 0)), std::numeric_limits<float>::min());
+    if (!std::isfinite(pad)) return false;
+    auto lower = [&](float x) { const float y = x - pad; return y < x ? y : std::nextafterf(x, -INFINITY); };
+    auto upper = [&](float x) { const float y = x + pad; return y > x ? y : std::nextafterf(x, INFINITY); };
+    Box rb; rb.reset();
+    if (out.root_ref & PT_REF_LEAF) { for (const PtFastLeaf &u : units) rb.grow(u.mn, u.mx); }
+    else { WideView nv{out.wnodes}; rb = nv.box(0, 0); rb.grow(nv.box(0, 1)); }
+    for (int k = 0; k < 3; k++) { out.root_min[k] = lower(rb.mn[k]); out.root_max[k] = upper(rb.mx[k]); }
+    {
+        WideView nv{out.wnodes};
+        for (uint32_t i = 0; i < out.wnodes.size() / 4; i++)
+            for (int side = 0; side < 2; side++) {
+                Box b = nv.box(i, side);
+                for (int k = 0; k < 3; k++) { b.mn[k] = lower(b.mn[k]); b.mx[k] = upper(b.mx[k]); }
+                nv.set_box(i, side, b);
+            }
+    }
+    for (int k = 0; k < 3; k++) if (!std::isfinite(out.root_min[k]) || !std::isfinite(out.root_max[k])) return false;
+    out.pad = pad;
+    out.safe_origin = (float)std::min(16.0 * biggest, 3.0e38);
+    return true;
 }
 
 // ---- quantised image ------------------------------------------------------------------------------------------------
@@ -441,5 +623,88 @@ bool pt_quantize_tree(const std::vector<PtFastLeaf> &leaves, const std::vector<f
     // Where they are (a chain of boxes shrinking geometrically), the rounded boxes would admit far more rays than the exact
     // ones: same results, much more work. Such scenes keep the exact image.
     if (grown && growth / (double)grown > 0.25) { qnodes.clear(); stream.clear(); return false; }
+    return true;
+}
+
+bool pt_quantize_nodes(const std::vector<float4> &wnodes, std::vector<uint4> &qnodes, float origin[3], float scale[3],
+                       uint32_t top_nodes, uint32_t &n_top) {
+    qnodes.clear(); n_top = 0;
+    const size_t n_nodes = wnodes.size() / 4;
+    if (n_nodes == 0) return false;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = 0; i < n_nodes; i++) {
+        const float4 *w = &wnodes[i * 4];
+        const float lo[2][3] = {{w[0].x, w[0].y, w[0].z}, {w[1].z, w[1].w, w[2].x}};
+        const float hi[2][3] = {{w[0].w, w[1].x, w[1].y}, {w[2].y, w[2].z, w[2].w}};
+        for (int c = 0; c < 2; c++)
+            for (int k = 0; k < 3; k++) {
+                if (!std::isfinite(lo[c][k]) || !std::isfinite(hi[c][k]) || lo[c][k] > hi[c][k]) return false;
+                mn[k] = std::min(mn[k], lo[c][k]); mx[k] = std::max(mx[k], hi[c][k]);
+            }
+    }
+    for (int k = 0; k < 3; k++) {
+        origin[k] = mn[k];
+        const double ext = (double)mx[k] - (double)mn[k];
+        float s = (float)(ext / 65535.0);
+        if (!std::isfinite(s)) return false;
+        if (ext > 0.0) {
+            if (!(s > 0.0f)) s = std::numeric_limits<float>::denorm_min();
+            int guard = 0;
+            while (std::fmaf(s, 65535.0f, origin[k]) < mx[k] && guard++ < 64) s = std::nextafterf(s, INFINITY);
+            if (std::fmaf(s, 65535.0f, origin[k]) < mx[k]) return false;
+        }
+        scale[k] = s;
+    }
+    auto plane_lo = [&](int k, float v) -> uint32_t {
+        if (!(scale[k] > 0.0f)) return 0u;
+        double q = std::floor(((double)v - (double)origin[k]) / (double)scale[k]);
+        uint32_t u = q <= 0.0 ? 0u : q >= 65535.0 ? 65535u : (uint32_t)q;
+        while (u > 0u && std::fmaf(scale[k], (float)u, origin[k]) > v) u--;
+        return u;
+    };
+    auto plane_hi = [&](int k, float v) -> uint32_t {
+        if (!(scale[k] > 0.0f)) return 0u;
+        double q = std::ceil(((double)v - (double)origin[k]) / (double)scale[k]);
+        uint32_t u = q <= 0.0 ? 0u : q >= 65535.0 ? 65535u : (uint32_t)q;
+        while (u < 65535u && std::fmaf(scale[k], (float)u, origin[k]) < v) u++;
+        return u;
+    };
+    std::vector<uint32_t> renum(n_nodes, 0xFFFFFFFFu);
+    {
+        std::vector<uint32_t> bfs; bfs.reserve(top_nodes);
+        bfs.push_back(0u);
+        for (size_t h = 0; h < bfs.size() && bfs.size() < top_nodes; h++) {
+            uint32_t refs[2]; std::memcpy(&refs[0], &wnodes[(size_t)bfs[h] * 4 + 3].x, 4); std::memcpy(&refs[1], &wnodes[(size_t)bfs[h] * 4 + 3].y, 4);
+            for (int c = 0; c < 2 && bfs.size() < top_nodes; c++)
+                if (!(refs[c] & PT_REF_LEAF)) bfs.push_back(refs[c]);
+        }
+        for (size_t k = 0; k < bfs.size(); k++) renum[bfs[k]] = (uint32_t)k;
+        n_top = (uint32_t)bfs.size();
+        uint32_t next = n_top;
+        for (size_t i = 0; i < n_nodes; i++) if (renum[i] == 0xFFFFFFFFu) renum[i] = next++;
+    }
+    qnodes.resize(n_nodes * 2);
+    double growth = 0.0; size_t grown = 0;
+    for (size_t i = 0; i < n_nodes; i++) {
+        const float4 *w = &wnodes[i * 4];
+        const float lo[2][3] = {{w[0].x, w[0].y, w[0].z}, {w[1].z, w[1].w, w[2].x}};
+        const float hi[2][3] = {{w[0].w, w[1].x, w[1].y}, {w[2].y, w[2].z, w[2].w}};
+        uint32_t refs[2]; std::memcpy(&refs[0], &w[3].x, 4); std::memcpy(&refs[1], &w[3].y, 4);
+        for (int c = 0; c < 2; c++) {
+            uint32_t ql[3], qh[3];
+            float dl[3], dh[3];
+            for (int k = 0; k < 3; k++) {
+                ql[k] = plane_lo(k, lo[c][k]); qh[k] = plane_hi(k, hi[c][k]);
+                dl[k] = std::fmaf(scale[k], (float)ql[k], origin[k]); dh[k] = std::fmaf(scale[k], (float)qh[k], origin[k]);
+            }
+            const uint32_t ref = (refs[c] & PT_REF_LEAF) ? refs[c] : renum[refs[c]];
+            qnodes[(size_t)renum[i] * 2 + c] = make_uint4(ql[0] | (ql[1] << 16), ql[2] | (qh[0] << 16), qh[1] | (qh[2] << 16), ref);
+            const double ax = (double)hi[c][0] - lo[c][0], ay = (double)hi[c][1] - lo[c][1], az = (double)hi[c][2] - lo[c][2];
+            const double a0 = 2.0 * (ax * ay + ay * az + az * ax);
+            const double bx = (double)dh[0] - dl[0], by = (double)dh[1] - dl[1], bz = (double)dh[2] - dl[2];
+            if (a0 > 0.0) { growth += std::min(2.0 * (bx * by + by * bz + bz * bx) / a0 - 1.0, 1e6); grown++; }
+        }
+    }
+    if (grown && growth / (double)grown > 0.25) { qnodes.clear(); return false; }       // a 16-bit grid is too coarse for this scene's boxes
     return true;
 }

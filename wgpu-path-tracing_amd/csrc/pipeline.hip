@@ -186,99 +186,6 @@ __global__ __launch_bounds__(TILE_WORDS) void k_scatter2(uint32_t tiles, const u
     else scatter_tile(blockIdx.x - tiles, count_ptr, nullptr, shadow, shadow_sums, shadow_queue, shadow_count);
 }
 
-// ---- compaction with a local sort by direction octant (ray_sort) -----------------------------------------------------
-// Same tiles, same tile offsets as k_scatter; inside each WINDOW of 16 ballot words (1024 queue slots) the survivors are
-// written grouped by the octant of their new direction (`shade` leaves three more ballot words per 64 slots: the signs of
-// d.x, d.y, d.z), each group in ascending slot order. A wave of the next traversal then holds rays of one octant whose
-// path ids lie within ~1024 of each other (so their state is still read from a 16-KB neighbourhood). The set of rays, their
-// arithmetic and their results do not depend on the order in which the queue lists them.
-constexpr int SORT_WINDOW = 16;          // words per window; 4 windows per wave, TILE_WORDS / 16 per tile
-// static LDS of k_scatter_sorted: two [TILE_WORDS][8] tables + the wave totals. At 1024 words that is 65.6 KB — more than the 64 KB
-// other targets allow, fine on gfx950's 160 KB; PT_TILE_WORDS is a -D parameter, so the bound is checked here
-static_assert(TILE_WORDS % 64 == 0 && TILE_WORDS <= 1024, "a tile is a workgroup of whole waves, at most 1024 threads");
-static_assert(2u * TILE_WORDS * 8u * sizeof(uint32_t) + (TILE_WAVES + 1u) * sizeof(uint32_t) <= 160u * 1024u, "k_scatter_sorted's LDS tables");
-
-__global__ __launch_bounds__(TILE_WORDS) void k_scatter_sorted(const uint32_t *__restrict__ count_ptr,
-                                                               const uint32_t *__restrict__ queue,
-                                                               const uint64_t *__restrict__ alive,
-                                                               const uint64_t *__restrict__ oct,      // [3][words_stride]
-                                                               uint32_t words_stride,
-                                                               const uint32_t *__restrict__ tile_sums,
-                                                               uint32_t *__restrict__ next_queue,
-                                                               uint32_t *__restrict__ next_count) {
-    __shared__ uint32_t wtot[TILE_WAVES];
-    __shared__ uint32_t tile_base;
-    __shared__ uint32_t s_off[TILE_WORDS][8];            // per word, per octant: where its first survivor of that octant goes
-    __shared__ uint32_t s_msk[TILE_WORDS][8];            // per word: alive, sign x, sign y, sign z (lo, hi halves)
-    const uint32_t count = *count_ptr;
-    const uint32_t nwords = (count + 63u) >> 6;
-    const uint32_t ntiles = (nwords + TILE_WORDS - 1) / TILE_WORDS;
-    if (blockIdx.x >= ntiles) {
-        if (ntiles == 0 && blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0;
-        return;
-    }
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t pre = 0;
-    for (uint32_t t = threadIdx.x; t < blockIdx.x; t += TILE_WORDS) pre += tile_sums[t];
-    for (int off = 32; off > 0; off >>= 1) pre += __shfl_down(pre, off);
-    if (lane == 0) wtot[wave] = pre;
-    __syncthreads();
-    if (threadIdx.x == 0) { uint32_t t = 0; for (int i = 0; i < TILE_WAVES; i++) t += wtot[i]; tile_base = t; }
-    __syncthreads();
-    const uint32_t base0 = tile_base;
-    __syncthreads();
-    const uint32_t w = blockIdx.x * TILE_WORDS + threadIdx.x;
-    const bool in = w < nwords;
-    const uint64_t m = in ? alive[w] : 0ull;
-    const uint64_t sx = in ? oct[w] : 0ull, sy = in ? oct[words_stride + w] : 0ull, sz = in ? oct[2u * words_stride + w] : 0ull;
-    const uint32_t c = (uint32_t)__popcll(m);
-    // exclusive scan of the words' survivor counts over the tile -> start of this word's window needs the window's first word
-    uint32_t inc = c;
-    for (int off = 1; off < 64; off <<= 1) { uint32_t v = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += v; }
-    if (lane == 63u) wtot[wave] = inc;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (uint32_t i = 0; i < wave; i++) wbase += wtot[i];
-    const uint32_t word_off = base0 + wbase + inc - c;                 // where this word's survivors would start, unsorted
-    if (blockIdx.x == ntiles - 1 && threadIdx.x == TILE_WORDS - 1) *next_count = word_off + c;
-    const uint32_t win_lane0 = lane & ~(uint32_t)(SORT_WINDOW - 1);    // first lane of this word's window
-    const uint32_t win_base = __shfl(word_off, (int)win_lane0);        // the window's survivors occupy [win_base, win_base + total)
-    // per octant: count in this word, exclusive scan over the window's 16 words, window total
-    uint32_t key_base = win_base;
-    for (uint32_t k = 0; k < 8u; k++) {
-        const uint64_t mk = m & ((k & 1u) ? sx : ~sx) & ((k & 2u) ? sy : ~sy) & ((k & 4u) ? sz : ~sz);
-        const uint32_t ck = (uint32_t)__popcll(mk);
-        uint32_t sc = ck;
-        for (int off = 1; off < SORT_WINDOW; off <<= 1) {
-            uint32_t v = __shfl_up(sc, off);
-            if ((lane & (SORT_WINDOW - 1)) >= (uint32_t)off) sc += v;
-        }
-        const uint32_t tot = __shfl(sc, (int)(win_lane0 + SORT_WINDOW - 1));
-        s_off[threadIdx.x][k] = key_base + sc - ck;
-        key_base += tot;
-    }
-    s_msk[threadIdx.x][0] = (uint32_t)m;  s_msk[threadIdx.x][1] = (uint32_t)(m >> 32);
-    s_msk[threadIdx.x][2] = (uint32_t)sx; s_msk[threadIdx.x][3] = (uint32_t)(sx >> 32);
-    s_msk[threadIdx.x][4] = (uint32_t)sy; s_msk[threadIdx.x][5] = (uint32_t)(sy >> 32);
-    s_msk[threadIdx.x][6] = (uint32_t)sz; s_msk[threadIdx.x][7] = (uint32_t)(sz >> 32);
-    __syncthreads();
-    // cooperative scatter: the wave walks its 64 words, lane = slot bit
-    const uint32_t w0 = blockIdx.x * TILE_WORDS + wave * 64u;
-    for (uint32_t j = 0; j < 64u; j++) {
-        const uint32_t *mj = s_msk[wave * 64u + j];
-        const uint64_t jm = ((uint64_t)mj[1] << 32) | mj[0];
-        if (jm == 0ull) continue;
-        if ((jm >> lane) & 1ull) {
-            const uint64_t jx = ((uint64_t)mj[3] << 32) | mj[2], jy = ((uint64_t)mj[5] << 32) | mj[4], jz = ((uint64_t)mj[7] << 32) | mj[6];
-            const uint32_t k = (uint32_t)((jx >> lane) & 1ull) | ((uint32_t)((jy >> lane) & 1ull) << 1) | ((uint32_t)((jz >> lane) & 1ull) << 2);
-            const uint64_t mk = jm & ((k & 1u) ? jx : ~jx) & ((k & 2u) ? jy : ~jy) & ((k & 4u) ? jz : ~jz);
-            const uint32_t below = (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
-            const uint32_t slot = (w0 + j) * 64u + lane;
-            next_queue[s_off[wave * 64u + j][k] + below] = queue ? queue[slot] : slot;
-        }
-    }
-}
-
 // pt.wgsl:751-761 for the batch's frames in ascending order
 __global__ __launch_bounds__(BLOCK) void k_accumulate(DevBand band, uint32_t frame0, uint32_t n_frames,
                                                       const float *__restrict__ L, uint32_t l_stride, float4 *__restrict__ out) {
@@ -423,22 +330,18 @@ void pt_launch_raygen_list(hipStream_t s, const ptmi_camera &cam, uint32_t n, co
 void pt_launch_compact(hipStream_t s, int tiles, const uint32_t *queue, const uint32_t *count,
                        const uint64_t *alive_mask, const uint64_t *shadow_mask, uint32_t *tile_sums,
                        uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_queue, uint32_t *shadow_count,
-                       unsigned long long *stats, uint32_t bounce, int do_scatter, const uint64_t *octant_masks,
-                       uint32_t octant_stride) {
+                       unsigned long long *stats, uint32_t bounce, int do_scatter) {
     uint32_t *shadow_sums = tile_sums + tiles;
     hipLaunchKernelGGL(k_tile_sums, dim3(tiles), dim3(TILE_WORDS), 0, s, count, alive_mask, shadow_mask, tile_sums,
                        shadow_sums, stats, bounce);
 #ifndef PT_NO_SCATTER2
-    if (do_scatter && shadow_mask && !octant_masks) {
+    if (do_scatter && shadow_mask) {
         hipLaunchKernelGGL(k_scatter2, dim3(2 * tiles), dim3(TILE_WORDS), 0, s, (uint32_t)tiles, count, queue, alive_mask, shadow_mask,
                            tile_sums, shadow_sums, next_queue, next_count, shadow_queue, shadow_count);
         return;
     }
 #endif
-    if (do_scatter && octant_masks)
-        hipLaunchKernelGGL(k_scatter_sorted, dim3(tiles), dim3(TILE_WORDS), 0, s, count, queue, alive_mask, octant_masks,
-                           octant_stride, tile_sums, next_queue, next_count);
-    else if (do_scatter)
+    if (do_scatter)
         hipLaunchKernelGGL(k_scatter, dim3(tiles), dim3(TILE_WORDS), 0, s, count, queue, alive_mask, tile_sums,
                            next_queue, next_count);
     if (shadow_mask)    // slots (not path ids) of the emitted shadow records, ascending

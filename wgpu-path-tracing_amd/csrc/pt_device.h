@@ -45,7 +45,16 @@ struct DevScene {
     // edge is not finite): such rays take the triangle test whose short reciprocal has no range test (pt_math.h)
     float tri_safe_dsum;
     uint32_t q_cached;          // the first q_cached quantised nodes are the top levels in breadth-first order (kept in LDS)
-    uint32_t leaf_bits;         // bits needed for the triangle count of the largest leaf (4 triangles -> 3): the work list's prefix sums
+    // OWN LEAVES (ptmi_options.leaves = 2, traverse_own.hip; own = 0: none of this is set). wnodes / tripos / qnodes / root_min / root_max
+    // then describe the library's own hierarchy over the triangles: padded boxes, tripos in LEAF order with the original triangle
+    // index in v0.w, n_own_tris entries; qnodes without a leaf stream. The tree as uploaded stays in ref_wnodes (its exact root box
+    // in ref_root_min / _max) with the triangle images in ORIGINAL order in ref_tripos: what `slow` rays walk.
+    uint32_t own, n_own_tris;
+    const float4 *ref_tripos;
+    const float4 *tri_leafbox;  // per ORIGINAL triangle index: (min.xyz, 0), (max.xyz, 0) of the reference leaf that lists it
+    float ref_root_min[3], ref_root_max[3];
+    float safe_origin;          // |o|_inf up to which the boxes' padding covers the rounding of the fused slab test
+    unsigned long long *verify_stat;    // += rays whose winner failed its reference leaf's box and were traced again
 };
 
 // ---- path state: 56 B per path, four streams indexed by path id ----
@@ -93,43 +102,32 @@ struct DevBand {
 struct ShadeParams {
     uint32_t bounce, max_bounces, do_mis;
     unsigned long long *stats;          // [1] += next-event samples counted but not traced (zero contribution)
-    uint64_t *octant_masks;             // ray_sort: per 64 slots the sign bits of the survivors' new direction, three arrays
-    uint32_t octant_stride;             //           octant_stride words apart (x, y, z); NULL: not wanted
     uint32_t emit_records;              // 1: an emissive hit does not add to L here; it leaves a record (SO.w = -2: nothing to trace)
                                         //    that `shadow` adds like an unoccluded light sample — all additions to L then happen in
                                         //    that one kernel, in bounce order, and `shadow` can run beside the next bounce's kernels.
                                         //    stats[3] += such records (they are not shadow rays)
-    // STATE FOLLOWS THE QUEUE (ptmi_options.state = 2; all NULL: the state stays in place, at the path's id). The state this
-    // launch READS is the DevPaths argument, at index q = queue[slot]; the survivors' new state goes to these buffers at index
-    // `slot` — dense in this bounce's queue — and the next queue lists slots instead of path ids, so the next bounce gathers its
-    // rays at the density of one bounce's survival rate (0.5 - 0.8) instead of the whole path's (0.07 by bounce 4 on Cornell).
-    // The radiance stays indexed by path id: pid_in[q] is the path whose state sits at q (NULL: q itself), pid_out[slot] its copy
-    // for the next bounce (NULL: not needed, slot is the path id — bounce 0).
-    float4 *O_out, *D_out; float2 *C_out;
-    const uint32_t *pid_in; uint32_t *pid_out;
 };
 
-enum { PT_VARIANT_GLOBAL = 1, PT_VARIANT_LDS = 2, PT_VARIANT_LDS_NODES = 3 };
+enum { PT_VARIANT_GLOBAL = 1, PT_VARIANT_LDS = 2, PT_VARIANT_LDS_NODES = 3,
+       // own leaves (traverse_own.hip): exact / quantised nodes in LDS, with (…_LDS) or without (…_NODES) the triangle images, or from memory
+       PT_VARIANT_OWN_LDS = 4, PT_VARIANT_OWN_LDS_NODES = 5, PT_VARIANT_OWN_QLDS = 6, PT_VARIANT_OWN_QLDS_NODES = 7,
+       PT_VARIANT_OWN_QGLOBAL = 8, PT_VARIANT_OWN_GLOBAL = 9 };
 
 struct TraverseConfig {
     int variant;            // PT_VARIANT_*
-    int stack_entries;      // 14 (node cache only), 16, 32 or 64
+    int stack_entries;      // 15 (two workgroups per CU only), 16, 32 or 64
     int cull;               // 0/1
     size_t lds_scene_bytes; // LDS variant: bytes of wnodes + tripos
     int wgs_per_cu;         // node cache: 2 (small trees, whole stack in LDS) or 1 (mid-size trees, spilling stacks)
     uint32_t *spill;        // global variant: per-lane overflow of the node stack, pt_spill_bytes(blocks) bytes
     int wants_spill;        // the variant needs one (the caller supplies `spill`: each concurrently running kernel its own)
     int quantized;          // global variant: walk the quantised image when the scene has one
-    int worklist;           // LDS variant: triangle tests through the per-wave work list (traverse.hip trace_wave_wl)
-    uint32_t *ticket;       // -DPT_DYNAMIC_CLAIM builds: this launch's chunk counter (one zeroed word in device memory); else unused
 };
 #ifndef PT_QCACHE_NODES
 #define PT_QCACHE_NODES 256      /* quantised nodes of the top levels staged in LDS per workgroup (8 KB) */
 #endif
 #define PT_SPILL_ENTRIES 64     /* >= the deepest node stack: upload rejects trees deeper than 62 */
 size_t pt_spill_bytes(int blocks);
-size_t pt_worklist_bytes(void);
-int pt_dynamic_claim(void);     // 1 in -DPT_DYNAMIC_CLAIM builds: every traversal launch needs TraverseConfig::ticket  // LDS a 1024-thread workgroup needs for its waves' work lists
 
 // ---- launchers (each enqueues on `s`; grids are persistent, sized by the caller) ----
 void pt_launch_raygen(hipStream_t s, int blocks, const ptmi_camera &cam, DevBand band, uint32_t frame0,
@@ -138,11 +136,15 @@ void pt_launch_raygen_list(hipStream_t s, const ptmi_camera &cam, uint32_t n, co
                            const uint32_t *ys, const uint32_t *frames, DevPaths p);
 void pt_launch_extend(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, DevPaths p,
                       const uint32_t *queue, const uint32_t *count, float2 *hits);
+void pt_launch_extend_own(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, DevPaths p,
+                          const uint32_t *queue, const uint32_t *count, float2 *hits);        // traverse_own.hip
 // (u, v) of n hit records, rebuilt the way `shade` does it (debug entry point of the parity tests)
 void pt_launch_hit_uv(hipStream_t s, uint32_t n, const DevScene &sc, DevPaths p, const float2 *hits, float2 *uv);
 // shadow_queue: slots of the shadow records to trace (NULL = slots 0..count-1), count = their number
 void pt_launch_shadow(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, DevPaths p,
                       DevShadow sh, const uint32_t *shadow_queue, const uint32_t *count, uint8_t *occluded_out);
+void pt_launch_shadow_own(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, DevPaths p,
+                          DevShadow sh, const uint32_t *shadow_queue, const uint32_t *count, uint8_t *occluded_out);
 void pt_launch_shade(hipStream_t s, int blocks, const DevScene &sc, DevPaths p, const uint32_t *queue,
                      const uint32_t *count, const float2 *hits, DevShadow sh, uint64_t *alive_mask,
                      uint64_t *shadow_mask, ShadeParams sp);
@@ -155,8 +157,7 @@ uint32_t pt_compact_tile_slots(void);
 void pt_launch_compact(hipStream_t s, int tiles, const uint32_t *queue, const uint32_t *count,
                        const uint64_t *alive_mask, const uint64_t *shadow_mask, uint32_t *tile_sums,
                        uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_queue, uint32_t *shadow_count,
-                       unsigned long long *stats, uint32_t bounce, int do_scatter, const uint64_t *octant_masks = nullptr,
-                       uint32_t octant_stride = 0);
+                       unsigned long long *stats, uint32_t bounce, int do_scatter);
 void pt_launch_accumulate(hipStream_t s, int blocks, DevBand band, uint32_t frame0, uint32_t n_frames,
                           const float *L, uint32_t l_stride, float4 *out);
 void pt_launch_blit(hipStream_t s, int blocks, uint32_t W, uint32_t H, const float4 *color, float4 *out_f32,

@@ -27,46 +27,27 @@ constexpr size_t kMaxPendingEvents = 4096;        // a caller that never synchro
 
 }  // namespace
 
-// One wavefront batch in flight: its buffers, and (options.overlap) the streams and events that let it run beside another.
+// The buffers of the wavefront batch in flight, and the second stream that lets `shadow` run beside the next bounce.
 struct Lane {
     size_t cap = 0;
     DevPaths paths{};
-    // second set of ray-state buffers and the path ids of both sets (ptmi_options.state = 2: the state follows the queue)
-    float4 *O2 = nullptr, *D2 = nullptr; float2 *C2 = nullptr; uint32_t *pid[2] = {nullptr, nullptr};
-    // ptmi_options.pipeline = 2: a second set of the buffers `raygen` writes (origin + RNG state, direction, radiance); batches alternate
-    // between paths.{O, D, L} and these, and batch k + 1's `raygen` runs on `pre` beside batch k
-    float4 *O_b = nullptr, *D_b = nullptr; float *L_b = nullptr;
-    hipStream_t pre = nullptr;
-    hipEvent_t ev_ray[2] = {nullptr, nullptr};      // recorded on `pre` behind a raygen: the batch's first kernel waits for it
-    hipEvent_t ev_use[2] = {nullptr, nullptr};      // recorded behind a batch's accumulate: its O / D / L may be overwritten
-    bool use_recorded[2] = {false, false};
-    uint64_t pre_seq = 0;                           // batches traced through the pipeline so far (parity = which buffer set)
     float2 *hits = nullptr;
-    DevShadow sh[2]{};                                 // shadow records, double-buffered by bounce parity (overlap >= 1)
+    DevShadow sh[2]{};                                 // shadow records, double-buffered by bounce parity (overlap)
     uint32_t *queue[2] = {nullptr, nullptr}, *sq[2] = {nullptr, nullptr};
-    uint64_t *alive = nullptr, *shadowm = nullptr, *octm = nullptr;   // octm: 3 x words (ray_sort)
+    uint64_t *alive = nullptr, *shadowm = nullptr;
     size_t mask_words = 0;
     uint32_t *word_off = nullptr, *counts = nullptr;
-    uint32_t *tickets = nullptr;          // -DPT_DYNAMIC_CLAIM builds: one chunk counter per traversal launch of a batch (zeroed per batch)
     uint32_t *d_spill = nullptr;          // node-stack overflow of the global traversal variant (128 MiB on 256 CUs; first use)
     uint32_t *d_spill_side = nullptr;     // ... of the `shadow` kernel when it runs beside `extend`
     uint8_t *d_occ = nullptr;
-    hipStream_t main = nullptr;           // overlap 3: this lane's own stream (else the context's stream is used)
     hipStream_t side = nullptr;           // `shadow` of bounce b beside the kernels of bounce b + 1
     hipEvent_t ev_ready = nullptr, ev_shadow[2] = {nullptr, nullptr};
-    hipEvent_t ev_mid = nullptr;          // recorded after the compaction of bounce 3: the other lane's next batch may start
-    hipEvent_t ev_done = nullptr;         // all kernels of the batch finished (accumulate, on the context's stream, waits for it)
-    hipEvent_t ev_free = nullptr;         // its accumulate finished: the buffers may be overwritten
-    bool mid_recorded = false, free_recorded = false;
 };
 
 struct ptmi_ctx {
     int device = 0, n_cu = 256;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    Lane lanes[2];
-    uint64_t batch_seq = 0;                            // batches launched so far (two lanes: batch k runs on lane k & 1)
-    bool last_two_lanes = false;                       // how the previous dispatch used the lanes
-    bool last_pipe = false;                            // ... and whether its camera rays came from the `pre` stream
+    Lane lane;
     mutable std::string err;
     bool alloc_oom = false;                            // the last failed batch allocation ran out of device memory
     ptmi_options opt{};
@@ -74,9 +55,12 @@ struct ptmi_ctx {
     // scene (bindings 1, 2, 4, 5, 6)
     void *d_tris = nullptr, *d_mats = nullptr, *d_lights = nullptr, *d_atlas = nullptr;
     float4 *d_wnodes = nullptr, *d_tripos = nullptr, *d_fast_wnodes = nullptr;
+    float4 *d_own_tripos = nullptr, *d_leafbox = nullptr;               // own leaves: leaf-ordered triangle images, per-triangle reference leaf boxes
     uint4 *d_qnodes = nullptr; uint32_t *d_leaf_stream = nullptr;        // quantised image of the rebuilt hierarchy (global variant)
     DevScene sc{};
     uint32_t bvh_depth = 0;
+    uint32_t own_depth = 0;                  // own leaves: levels of the library's hierarchy (the uploaded tree's: bvh_depth)
+    bool own_quant = false;                  // ... and whether it has a quantised image
     bool have_scene = false;
     size_t lds_scene_bytes = 0;
 
@@ -98,19 +82,7 @@ namespace {
 
 constexpr int kStatsWords = 8 + 64;
 constexpr int kShadowCount = 72;          // slot of the shadow-queue length in ctx->counts (80 words)
-constexpr int kTickets = 160;             // per lane: extend(b) uses word b, shadow(b) word 64 + b, the per-stage entry points word 159
-constexpr int kPipeCount = 76;            // pipeline = 2: slots of the bounce-0 queue length, one per buffer-set parity
 constexpr size_t kLdsMax = 160 * 1024;
-#ifndef PT_STATE_DEFAULT
-#define PT_STATE_DEFAULT 1             /* what ptmi_options.state = 0 means: 1 in place, 2 the state follows the queue (measured: profiles/README.md) */
-#endif
-#ifndef PT_PIPELINE_DEFAULT
-#define PT_PIPELINE_DEFAULT 1          /* what ptmi_options.pipeline = 0 means: 1 off, 2 the next batch's raygen on its own stream (measured: profiles/README.md) */
-#endif
-#ifndef PT_WORKLIST_DEFAULT
-#define PT_WORKLIST_DEFAULT 0          /* what ptmi_options.worklist = 0 means (measured: profiles/README.md) */
-#endif
-
 int fail(const ptmi_ctx *c, int code, const char *fmt, ...) {
     char buf[512];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
@@ -124,7 +96,7 @@ template <class T> void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; }
 
 void default_options(ptmi_options &o) {
     std::memset(&o, 0, sizeof o);
-    o.max_bounces = 8; o.do_mis = 1; o.cull = 1; o.traversal = PTMI_TRAVERSAL_AUTO; o.ray_sort = 2; o.overlap = 2;
+    o.max_bounces = 8; o.do_mis = 1; o.cull = 1; o.traversal = PTMI_TRAVERSAL_AUTO; o.overlap = 2;
 }
 
 hipEvent_t get_event(ptmi_ctx *c) {
@@ -195,36 +167,25 @@ struct Timed {
 
 void free_batch(Lane &ln) {
     dfree(ln.paths.O); dfree(ln.paths.D); dfree(ln.paths.C); dfree(ln.paths.L);
-    dfree(ln.O2); dfree(ln.D2); dfree(ln.C2); dfree(ln.pid[0]); dfree(ln.pid[1]);
-    dfree(ln.O_b); dfree(ln.D_b); dfree(ln.L_b); ln.use_recorded[0] = ln.use_recorded[1] = false;
     dfree(ln.hits);
     for (int k = 0; k < 2; k++) { dfree(ln.sh[k].SO); ln.sh[k].SD = nullptr; ln.sh[k].SC = nullptr; dfree(ln.sq[k]); }
-    dfree(ln.queue[0]); dfree(ln.queue[1]); dfree(ln.alive); dfree(ln.shadowm); dfree(ln.octm); dfree(ln.word_off); dfree(ln.d_occ);
+    dfree(ln.queue[0]); dfree(ln.queue[1]); dfree(ln.alive); dfree(ln.shadowm); dfree(ln.word_off); dfree(ln.d_occ);
     ln.cap = 0;
 }
 
 // everything the library has in flight, on every stream it owns
 hipError_t sync_all(ptmi_ctx *c) {
     hipError_t e = c->stream ? hipStreamSynchronize(c->stream) : hipSuccess;
-    for (Lane &ln : c->lanes) {
-        if (e == hipSuccess && ln.main) e = hipStreamSynchronize(ln.main);
-        if (e == hipSuccess && ln.side) e = hipStreamSynchronize(ln.side);
-        if (e == hipSuccess && ln.pre) e = hipStreamSynchronize(ln.pre);
-    }
-    if (e == hipSuccess && c->stream) e = hipStreamSynchronize(c->stream);      // accumulates that waited for a lane
+    if (e == hipSuccess && c->lane.side) e = hipStreamSynchronize(c->lane.side);
+    if (e == hipSuccess && c->stream) e = hipStreamSynchronize(c->stream);      // the accumulate that waited for the side stream
     return e;
 }
 
-// bytes of device memory a path of a batch takes in ensure_capacity (state 56 + hit 8 + 2 x (record 44 + index 4) + 2 queues + masks;
-// with the state following the queue a second set of ray state, 40, and two path-id lists)
+// bytes of device memory a path of a batch takes in ensure_capacity (state 56 + hit 8 + 2 x (record 44 + index 4) + 2 queues + masks)
 constexpr size_t kBytesPerPath = 16 + 16 + 8 + 16 + 8 + 2 * (16 + 16 + sizeof(rgb_sc) + 4) + 2 * 4 + 1 + 1;
-constexpr size_t kBytesPerPathState2 = 16 + 16 + 8 + 2 * 4;
-constexpr size_t kBytesPerPathPipeline = 16 + 16 + 16;
 
-int ensure_capacity(ptmi_ctx *c, Lane &ln, size_t n, bool state2, bool pipe = false) {
-    if (n <= ln.cap && (!state2 || ln.O2) && (!pipe || ln.O_b)) return PTMI_OK;
-    state2 = state2 || ln.O2; pipe = pipe || ln.O_b;         // what the lane had, it keeps
-    if (n < ln.cap) n = ln.cap;
+int ensure_capacity(ptmi_ctx *c, Lane &ln, size_t n) {
+    if (n <= ln.cap) return PTMI_OK;
     HIP_TRY(c, sync_all(c));
     free_batch(ln);
     size_t cap = (n + 1023) & ~(size_t)1023;
@@ -238,8 +199,6 @@ int ensure_capacity(ptmi_ctx *c, Lane &ln, size_t n, bool state2, bool pipe = fa
         return fail(c, PTMI_E_HIP, "hipMalloc of %zu bytes for a batch of %zu paths failed: %s", (size_t)(bytes), cap, hipGetErrorString(e_)); } } while (0)
     ALLOC(ln.paths.O, cap * 16); ALLOC(ln.paths.D, cap * 16);
     ALLOC(ln.paths.C, cap * 8); ALLOC(ln.paths.L, cap * 16);      // room for either stride
-    if (pipe) { ALLOC(ln.O_b, cap * 16); ALLOC(ln.D_b, cap * 16); ALLOC(ln.L_b, cap * 16); }
-    if (state2) { ALLOC(ln.O2, cap * 16); ALLOC(ln.D2, cap * 16); ALLOC(ln.C2, cap * 8); ALLOC(ln.pid[0], cap * 4); ALLOC(ln.pid[1], cap * 4); }
     ALLOC(ln.hits, cap * 8);
     for (int k = 0; k < 2; k++) {
         ALLOC(ln.sh[k].SO, cap * (16 + 16 + sizeof(rgb_sc)));
@@ -247,8 +206,7 @@ int ensure_capacity(ptmi_ctx *c, Lane &ln, size_t n, bool state2, bool pipe = fa
         ALLOC(ln.sq[k], cap * 4);
     }
     ALLOC(ln.queue[0], cap * 4); ALLOC(ln.queue[1], cap * 4);
-    ALLOC(ln.alive, words * 8); ALLOC(ln.shadowm, words * 8);
-    ALLOC(ln.octm, 3 * words * 8); ln.mask_words = words;
+    ALLOC(ln.alive, words * 8); ALLOC(ln.shadowm, words * 8); ln.mask_words = words;
     ALLOC(ln.word_off, 2 * tiles * 4);
     ALLOC(ln.d_occ, cap);
 #undef ALLOC
@@ -270,7 +228,19 @@ struct Built {
     uint32_t q_top = 0;                      // quantised nodes numbered breadth-first at the front (LDS-resident in the kernel)
     uint32_t max_leaf_tris = 0;
     bool gpu_tree = false;                   // the rebuilt hierarchy came from the device (ptmi_options.tree_builder = 2)
+    // own leaves (ptmi_options.leaves = 2)
+    bool own = false;
+    PtOwnTree own_tree;
+    std::vector<uint4> own_qnodes;           // quantised nodes of own_tree (empty: a 16-bit grid does not resolve this scene)
+    std::vector<float4> leafbox;             // 2 float4 per triangle (original index): its reference leaf's box
 };
+
+#ifndef PT_LEAVES_DEFAULT
+#define PT_LEAVES_DEFAULT 2            /* what ptmi_options.leaves = 0 means (measured: profiles/README.md) */
+#endif
+#ifndef PT_LEAF_TRIS_DEFAULT
+#define PT_LEAF_TRIS_DEFAULT 2         /* ... and ptmi_options.leaf_tris = 0 */
+#endif
 
 uint32_t leaf_ref(const ptmi_bvh_node &n) {
     return PT_REF_LEAF | ((n.triangle_count - 1u) << PT_LEAF_OFF_BITS) | n.triangle_offset;
@@ -354,7 +324,38 @@ int build_image(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_
                     nested = nested && nodes[ch].aabb_min[k] >= n.aabb_min[k] && nodes[ch].aabb_max[k] <= n.aabb_max[k];
         }
     }
-    if (nested && leaves.size() >= 2 && !c->opt.keep_reference_tree) {
+    const uint32_t leaves_mode = c->opt.leaves ? c->opt.leaves : (uint32_t)PT_LEAVES_DEFAULT;
+    if (nested && leaves_mode == 2u && !c->opt.keep_reference_tree) {
+        // The library's own leaves (fast_tree.h). What the reference's semantics need from the uploaded tree is kept beside them: the
+        // tree itself (slow rays walk it) and, per triangle, the box of the leaf that lists it (the winner's verification).
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<uint32_t> which;
+        which.reserve(nt);
+        b.leafbox.assign((size_t)nt * 2, make_float4(0, 0, 0, 0));
+        for (const PtFastLeaf &l : leaves) {            // (leaf ranges ascend and do not overlap: checked above)
+            const uint32_t first = l.ref & PT_LEAF_OFF_MASK;
+            for (uint32_t k = 0; k < l.weight; k++) {
+                which.push_back(first + k);
+                b.leafbox[2 * (size_t)(first + k)] = make_float4(l.mn[0], l.mn[1], l.mn[2], 0.0f);
+                b.leafbox[2 * (size_t)(first + k) + 1] = make_float4(l.mx[0], l.mx[1], l.mx[2], 0.0f);
+            }
+        }
+        std::sort(which.begin(), which.end());
+        const uint32_t k_max = c->opt.leaf_tris ? c->opt.leaf_tris : (uint32_t)PT_LEAF_TRIS_DEFAULT;
+        // small scenes: at most 14 levels, so that a lane's whole node stack fits the 15 LDS entries of two workgroups per CU
+        const uint32_t limit = which.size() <= 2048 ? 14u : 60u;
+        b.own = pt_build_own_tree(tris, which, k_max, limit, b.own_tree);
+        if (b.own) {
+            float qo[3], qs[3];
+            if (pt_quantize_nodes(b.own_tree.wnodes, b.own_qnodes, qo, qs, PT_QCACHE_NODES, b.q_top))
+                for (int k = 0; k < 3; k++) { b.q_origin[k] = qo[k]; b.q_scale[k] = qs[k]; }
+            else b.own_qnodes.clear();
+        } else {
+            b.leafbox.clear();
+        }
+        b.tree_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (nested && leaves.size() >= 2 && !c->opt.keep_reference_tree && !b.own) {
         const auto t0 = std::chrono::steady_clock::now();
         // tree_builder = 2: on the device (gpu_tree.hip); the host builder when that is not wanted, not possible (ptmi_debug_image_stats
         // has no device) or refused
@@ -397,8 +398,68 @@ int build_image(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_
 // per-lane LDS entries: the node stack (<= depth - 2 deferred siblings) plus room for filed leaves
 int stack_entries_for(uint32_t depth) { return depth + 2 <= 16 ? 16 : depth + 2 <= 24 ? 24 : depth + 2 <= 32 ? 32 : 64; }
 
+// Own leaves (traverse_own.hip): which memory variant a kernel runs as. Sizes: exact nodes 64 B, quantised 32 B, triangle images
+// 48 B, 4 KB of LDS per stack entry of a 1024-thread workgroup. PTMI_OWN_EXTEND / PTMI_OWN_SHADOW (a PT_VARIANT_OWN_* number) override
+// the choice where it fits — for same-box A/Bs, not for users.
+TraverseConfig own_config(const ptmi_ctx *c, bool closest_hit) {
+    TraverseConfig cfg{};
+    cfg.cull = c->opt.cull ? 1 : 0;
+    cfg.lds_scene_bytes = c->lds_scene_bytes;
+    cfg.wgs_per_cu = 1;
+    const uint32_t depth = std::max(c->own_depth, c->bvh_depth);      // slow rays walk the uploaded tree on the same stacks
+    const size_t ne = (size_t)c->sc.n_wnodes * 64, nq = (size_t)c->sc.n_wnodes * 32, tb = (size_t)c->sc.n_own_tris * 48;
+    const bool quant = c->own_quant;
+    const int full_stack = depth + 2 <= 16 ? 16 : depth + 2 <= 32 ? 32 : 0;
+    const size_t full_b = (size_t)full_stack * 4096, two_b = (size_t)15 * 4096, spill_b = (size_t)16 * 4096;
+    const bool two_ok = depth + 1 <= 15;                              // the whole node stack in 15 entries
+    auto fits = [&](int variant, int wgs) -> bool {
+        switch (variant) {
+        case PT_VARIANT_OWN_LDS: return full_stack && ne + tb + full_b <= kLdsMax;
+        case PT_VARIANT_OWN_QLDS: return quant && full_stack && nq + tb + full_b <= kLdsMax;
+        case PT_VARIANT_OWN_LDS_NODES: return wgs == 2 ? two_ok && ne + two_b <= kLdsMax / 2 : ne + spill_b <= kLdsMax;
+        case PT_VARIANT_OWN_QLDS_NODES: return quant && (wgs == 2 ? two_ok && nq + two_b <= kLdsMax / 2 : nq + spill_b <= kLdsMax);
+        case PT_VARIANT_OWN_QGLOBAL: return quant;
+        case PT_VARIANT_OWN_GLOBAL: return true;
+        }
+        return false;
+    };
+    auto take = [&](int variant, int wgs) {
+        cfg.variant = variant; cfg.wgs_per_cu = wgs;
+        const bool lds_full = variant == PT_VARIANT_OWN_LDS || variant == PT_VARIANT_OWN_QLDS;
+        const bool global = variant == PT_VARIANT_OWN_QGLOBAL || variant == PT_VARIANT_OWN_GLOBAL;
+        cfg.stack_entries = lds_full ? full_stack : wgs == 2 ? 15 : 16;
+        cfg.wants_spill = (global || (!lds_full && wgs == 1)) ? 1 : 0;
+        cfg.quantized = (variant == PT_VARIANT_OWN_QLDS || variant == PT_VARIANT_OWN_QLDS_NODES || variant == PT_VARIANT_OWN_QGLOBAL) ? 1 : 0;
+    };
+    const bool big = c->lds_scene_bytes > ((size_t)4 << 20);         // beyond an XCD's L2: the quantised nodes pay (traverse_config below)
+    if (c->opt.traversal == PTMI_TRAVERSAL_GLOBAL) { take(quant ? PT_VARIANT_OWN_QGLOBAL : PT_VARIANT_OWN_GLOBAL, 1); return cfg; }
+    if (c->opt.traversal == PTMI_TRAVERSAL_GLOBAL_EXACT) { take(PT_VARIANT_OWN_GLOBAL, 1); return cfg; }
+    if (c->opt.traversal == PTMI_TRAVERSAL_LDS) {
+        if (fits(PT_VARIANT_OWN_LDS, 1)) take(PT_VARIANT_OWN_LDS, 1);
+        else if (fits(PT_VARIANT_OWN_QLDS, 1)) take(PT_VARIANT_OWN_QLDS, 1);
+        else take(PT_VARIANT_OWN_GLOBAL, 1);                          // the caller reports that it does not fit
+        return cfg;
+    }
+    if (const char *e = std::getenv(closest_hit ? "PTMI_OWN_EXTEND" : "PTMI_OWN_SHADOW")) {
+        const int v = std::atoi(e) % 10, w = std::atoi(e) >= 10 ? 2 : 1;        // e.g. 7 = quantised nodes, one workgroup; 17 = two
+        if (fits(v, w)) { take(v, w); return cfg; }
+    }
+    struct Pick { int variant, wgs; };
+    // closest hit: issue-bound, gains from the second workgroup per CU; any hit: tests fewer boxes per triangle, gains from resident triangles
+    static const Pick closest[] = {{PT_VARIANT_OWN_LDS_NODES, 2}, {PT_VARIANT_OWN_QLDS_NODES, 2}, {PT_VARIANT_OWN_LDS, 1}, {PT_VARIANT_OWN_QLDS, 1},
+                                   {PT_VARIANT_OWN_QLDS_NODES, 1}, {PT_VARIANT_OWN_LDS_NODES, 1}};
+    static const Pick any[] = {{PT_VARIANT_OWN_LDS, 1}, {PT_VARIANT_OWN_QLDS, 1}, {PT_VARIANT_OWN_QLDS_NODES, 1}, {PT_VARIANT_OWN_LDS_NODES, 1}};
+    if (!big) {
+        if (closest_hit) { for (const Pick &p : closest) if (fits(p.variant, p.wgs)) { take(p.variant, p.wgs); return cfg; } }
+        else for (const Pick &p : any) if (fits(p.variant, p.wgs)) { take(p.variant, p.wgs); return cfg; }
+    }
+    take((quant && big) ? PT_VARIANT_OWN_QGLOBAL : PT_VARIANT_OWN_GLOBAL, 1);
+    return cfg;
+}
+
 // closest_hit: the extend kernel may take the node-cache variant (two workgroups per CU) when it fits
 TraverseConfig traverse_config(const ptmi_ctx *c, bool closest_hit) {
+    if (c->sc.own) return own_config(c, closest_hit);
     TraverseConfig cfg{};
     cfg.stack_entries = stack_entries_for(c->bvh_depth);
     cfg.cull = c->opt.cull ? 1 : 0;
@@ -426,9 +487,6 @@ TraverseConfig traverse_config(const ptmi_ctx *c, bool closest_hit) {
         cfg.variant = PT_VARIANT_LDS_NODES; cfg.stack_entries = small_stack;
     } else if (fits) {
         cfg.variant = PT_VARIANT_LDS; cfg.stack_entries = lds_stack;
-        // the per-wave work list of triangle tests (traverse.hip trace_wave_wl): 16-entry stacks only, and room for the rings
-        const bool wl_on = c->opt.worklist == 2 || (c->opt.worklist == 0 && PT_WORKLIST_DEFAULT);
-        cfg.worklist = wl_on && lds_stack == 16 && c->lds_scene_bytes + (size_t)16 * 1024 * 4 + pt_worklist_bytes() <= kLdsMax;
     }
     else if (have && closest_hit && c->opt.traversal == PTMI_TRAVERSAL_AUTO &&
              (size_t)c->sc.n_wnodes * 64 + (size_t)16 * 1024 * 4 <= kLdsMax) {
@@ -439,6 +497,11 @@ TraverseConfig traverse_config(const ptmi_ctx *c, bool closest_hit) {
     else cfg.variant = PT_VARIANT_GLOBAL;
     if (cfg.variant == PT_VARIANT_GLOBAL) { cfg.stack_entries = 16; cfg.wants_spill = 1; }   // deeper stacks spill
     return cfg;
+}
+
+// the radiance sits at 16-byte stride beside kernels that wait on node fetches from memory (pt_device.h DevPaths)
+bool walks_memory_quantised(const TraverseConfig &cfg) {
+    return cfg.quantized && (cfg.variant == PT_VARIANT_GLOBAL || cfg.variant == PT_VARIANT_OWN_QGLOBAL);
 }
 
 int check_ready(ptmi_ctx *c, bool need_output) {
@@ -520,26 +583,17 @@ int ptmi_create(int device_ordinal, ptmi_ctx **out) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         bool ok = true;
-        for (Lane &ln : c->lanes) {
-            ok = ok && hipStreamCreateWithFlags(&ln.main, hipStreamNonBlocking) == hipSuccess;
+        Lane &ln = c->lane;
 #if defined(PT_SIDE_LOW_PRIORITY)
-            ok = ok && hipStreamCreateWithPriority(&ln.side, hipStreamNonBlocking, lo) == hipSuccess;
+        ok = ok && hipStreamCreateWithPriority(&ln.side, hipStreamNonBlocking, lo) == hipSuccess;
 #elif defined(PT_SIDE_NORMAL_PRIORITY)
-            ok = ok && hipStreamCreateWithFlags(&ln.side, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipStreamCreateWithFlags(&ln.side, hipStreamNonBlocking) == hipSuccess;
 #else
-            ok = ok && hipStreamCreateWithPriority(&ln.side, hipStreamNonBlocking, hi) == hipSuccess;
+        ok = ok && hipStreamCreateWithPriority(&ln.side, hipStreamNonBlocking, hi) == hipSuccess;
 #endif
-            // The `pre` stream (ptmi_options.pipeline) is created at the LOWEST priority, for two reasons: its `raygen` is meant to fill
-            // idle wave slots, never to take them; and the runtime multiplexes streams of one priority onto a few hardware queues
-            // (4 by default) — a normal-priority `pre` landed on the caller's own queue and ran in order behind its kernels
-            // (profiles/r03_pipeline/timeline_same_queue.txt) — while another priority level has hardware queues of its own.
-            ok = ok && hipStreamCreateWithPriority(&ln.pre, hipStreamNonBlocking, lo) == hipSuccess;
-            for (hipEvent_t *e : {&ln.ev_ready, &ln.ev_shadow[0], &ln.ev_shadow[1], &ln.ev_mid, &ln.ev_done, &ln.ev_free,
-                                  &ln.ev_ray[0], &ln.ev_ray[1], &ln.ev_use[0], &ln.ev_use[1]})
-                ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
-            ok = ok && hipMalloc(&ln.counts, 80 * sizeof(uint32_t)) == hipSuccess;
-            ok = ok && hipMalloc(&ln.tickets, kTickets * sizeof(uint32_t)) == hipSuccess;
-        }
+        for (hipEvent_t *e : {&ln.ev_ready, &ln.ev_shadow[0], &ln.ev_shadow[1]})
+            ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipMalloc(&ln.counts, 80 * sizeof(uint32_t)) == hipSuccess;
         if (!ok) { ptmi_destroy(c); return fail(nullptr, PTMI_E_HIP, "stream / event creation failed"); }
     }
     if (hipMalloc(&c->d_stats, kStatsWords * sizeof(unsigned long long)) != hipSuccess ||
@@ -557,17 +611,15 @@ int ptmi_destroy(ptmi_ctx *c) {
     drain_events(c);
     for (hipEvent_t e : c->in_flight) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-    for (Lane &ln : c->lanes) {
+    {
+        Lane &ln = c->lane;
         free_batch(ln);
-        dfree(ln.counts); dfree(ln.tickets); dfree(ln.d_spill); dfree(ln.d_spill_side);
-        for (hipEvent_t e : {ln.ev_ready, ln.ev_shadow[0], ln.ev_shadow[1], ln.ev_mid, ln.ev_done, ln.ev_free,
-                             ln.ev_ray[0], ln.ev_ray[1], ln.ev_use[0], ln.ev_use[1]}) if (e) (void)hipEventDestroy(e);
-        if (ln.pre) (void)hipStreamDestroy(ln.pre);
+        dfree(ln.counts); dfree(ln.d_spill); dfree(ln.d_spill_side);
+        for (hipEvent_t e : {ln.ev_ready, ln.ev_shadow[0], ln.ev_shadow[1]}) if (e) (void)hipEventDestroy(e);
         if (ln.side) (void)hipStreamDestroy(ln.side);
-        if (ln.main) (void)hipStreamDestroy(ln.main);
     }
     dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_atlas); dfree(c->d_wnodes); dfree(c->d_tripos);
-    dfree(c->d_fast_wnodes); dfree(c->d_qnodes); dfree(c->d_leaf_stream);
+    dfree(c->d_fast_wnodes); dfree(c->d_qnodes); dfree(c->d_leaf_stream); dfree(c->d_own_tripos); dfree(c->d_leafbox);
     dfree(c->d_out_own); dfree(c->d_stats); dfree(c->d_blit_f32); dfree(c->d_blit_u8);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -596,51 +648,71 @@ int ptmi_upload_scene(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const
     // Allocate and fill the new buffers first; the context keeps its previous scene until all of them exist.
     const auto t_copy = clk::now();
     void *n_tris = nullptr, *n_mats = nullptr, *n_lights = nullptr;
-    float4 *n_wnodes = nullptr, *n_tripos = nullptr, *n_fast = nullptr;
+    float4 *n_wnodes = nullptr, *n_tripos = nullptr, *n_fast = nullptr, *n_own_tripos = nullptr, *n_leafbox = nullptr;
     uint4 *n_qnodes = nullptr; uint32_t *n_stream = nullptr;
-    const bool quant = !b.qnodes.empty();
+    const bool own = b.own;
+    const std::vector<uint4> &qn = own ? b.own_qnodes : b.qnodes;
+    const bool quant = !qn.empty();
     auto up = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
         if (bytes == 0) { hipError_t e = hipMalloc(dst, 16); if (e != hipSuccess) return e; return hipMemset(*dst, 0, 16); }
         hipError_t e = hipMalloc(dst, bytes); if (e != hipSuccess) return e;
         return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     };
-    const bool fast = !b.fast_wnodes.empty();
+    // n_fast: the hierarchy the regular rays walk when it is not the uploaded one — rebuilt over the reference's leaves, or the own tree
+    const std::vector<float4> &walk = own ? b.own_tree.wnodes : b.fast_wnodes;
+    const bool fast = own || !b.fast_wnodes.empty();
     hipError_t e = up(&n_tris, tris, (size_t)nt * sizeof(ptmi_triangle));
     if (e == hipSuccess) e = up(&n_mats, mats, (size_t)nm * sizeof(ptmi_material));
     if (e == hipSuccess) e = up(&n_lights, lights, (size_t)nl * sizeof(ptmi_light));
     if (e == hipSuccess) e = up(reinterpret_cast<void **>(&n_wnodes), b.wnodes.data(), b.wnodes.size() * 16);
     if (e == hipSuccess) e = up(reinterpret_cast<void **>(&n_tripos), b.tripos.data(), b.tripos.size() * 16);
-    if (e == hipSuccess && fast) e = up(reinterpret_cast<void **>(&n_fast), b.fast_wnodes.data(), b.fast_wnodes.size() * 16);
-    if (e == hipSuccess && quant) e = up(reinterpret_cast<void **>(&n_qnodes), b.qnodes.data(), b.qnodes.size() * 16);
-    if (e == hipSuccess && quant) e = up(reinterpret_cast<void **>(&n_stream), b.leaf_stream.data(), b.leaf_stream.size() * 4);
+    if (e == hipSuccess && fast) e = up(reinterpret_cast<void **>(&n_fast), walk.data(), walk.size() * 16);
+    if (e == hipSuccess && own) e = up(reinterpret_cast<void **>(&n_own_tripos), b.own_tree.tripos.data(), b.own_tree.tripos.size() * 16);
+    if (e == hipSuccess && own) e = up(reinterpret_cast<void **>(&n_leafbox), b.leafbox.data(), b.leafbox.size() * 16);
+    if (e == hipSuccess && quant) e = up(reinterpret_cast<void **>(&n_qnodes), qn.data(), qn.size() * 16);
+    if (e == hipSuccess && quant && !own) e = up(reinterpret_cast<void **>(&n_stream), b.leaf_stream.data(), b.leaf_stream.size() * 4);
     if (e != hipSuccess) {
         dfree(n_tris); dfree(n_mats); dfree(n_lights); dfree(n_wnodes); dfree(n_tripos); dfree(n_fast); dfree(n_qnodes); dfree(n_stream);
+        dfree(n_own_tripos); dfree(n_leafbox);
         return fail(c, PTMI_E_HIP, "scene upload failed: %s (the previous scene, if any, is still in place)", hipGetErrorString(e));
     }
     HIP_TRY(c, sync_all(c));                  // nothing in flight reads the old buffers any more
     dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_wnodes); dfree(c->d_tripos); dfree(c->d_fast_wnodes);
-    dfree(c->d_qnodes); dfree(c->d_leaf_stream);
+    dfree(c->d_qnodes); dfree(c->d_leaf_stream); dfree(c->d_own_tripos); dfree(c->d_leafbox);
     c->d_qnodes = n_qnodes; c->d_leaf_stream = n_stream;
     c->d_tris = n_tris; c->d_mats = n_mats; c->d_lights = n_lights;
     c->d_wnodes = n_wnodes; c->d_tripos = n_tripos; c->d_fast_wnodes = n_fast;
+    c->d_own_tripos = n_own_tripos; c->d_leafbox = n_leafbox;
     DevScene &s = c->sc;
     s.tris = static_cast<const ptmi_triangle *>(c->d_tris); s.n_tris = nt;
     s.mats = static_cast<const ptmi_material *>(c->d_mats); s.n_mats = nm;
     s.lights = static_cast<const ptmi_light *>(c->d_lights); s.n_lights = nl;
     s.ref_wnodes = c->d_wnodes; s.ref_root_ref = b.root_ref; s.has_fast = fast ? 1u : 0u;
     s.wnodes = fast ? c->d_fast_wnodes : c->d_wnodes;
-    s.n_wnodes = (uint32_t)((fast ? b.fast_wnodes.size() : b.wnodes.size()) / 4);
-    s.tripos = c->d_tripos;
+    s.n_wnodes = (uint32_t)((fast ? walk.size() : b.wnodes.size()) / 4);
+    s.tripos = own ? c->d_own_tripos : c->d_tripos;
+    s.ref_tripos = c->d_tripos;
     s.qnodes = c->d_qnodes; s.leaf_stream = c->d_leaf_stream;
     for (int k = 0; k < 3; k++) { s.q_origin[k] = b.q_origin[k]; s.q_scale[k] = b.q_scale[k]; }
     s.q_cached = b.q_top;
-    s.leaf_bits = 0; while ((1u << s.leaf_bits) <= b.max_leaf_tris) s.leaf_bits++;      // counts 0 .. max need that many bits
     s.tri_safe_dsum = b.tri_safe_dsum;
-    for (int k = 0; k < 3; k++) { s.root_min[k] = b.root_min[k]; s.root_max[k] = b.root_max[k]; }
-    s.root_ref = fast ? b.fast_root : b.root_ref;
+    for (int k = 0; k < 3; k++) {
+        s.ref_root_min[k] = b.root_min[k]; s.ref_root_max[k] = b.root_max[k];
+        s.root_min[k] = own ? b.own_tree.root_min[k] : b.root_min[k]; s.root_max[k] = own ? b.own_tree.root_max[k] : b.root_max[k];
+    }
+    s.root_ref = own ? b.own_tree.root_ref : fast ? b.fast_root : b.root_ref;
+    s.own = own ? 1u : 0u;
+    s.n_own_tris = own ? (uint32_t)(b.own_tree.tripos.size() / 3) : 0u;
+    s.tri_leafbox = c->d_leafbox;
+    s.safe_origin = own ? b.own_tree.safe_origin : 0.0f;
+    s.verify_stat = c->d_stats + 4;
     c->bvh_depth = std::max(b.depth, b.fast_depth);           // stacks must hold either tree (irregular rays use the uploaded one)
-    c->lds_scene_bytes = (size_t)s.n_wnodes * 64 + b.tripos.size() * 16;
+    c->own_depth = own ? b.own_tree.depth : 0u;
+    c->own_quant = own && quant;
+    c->lds_scene_bytes = (size_t)s.n_wnodes * 64 + (own ? b.own_tree.tripos.size() : b.tripos.size()) * 16;
     c->have_scene = true;
+    c->st.leaves_used = own ? 2u : 1u;
+    c->st.leaf_tris_used = own ? b.own_tree.max_leaf_tris : b.max_leaf_tris;
     c->st.upload_copy_ms = ms_since(t_copy);
     c->st.upload_tree_ms = b.tree_ms;
     c->st.upload_ms = ms_since(t_start);
@@ -684,12 +756,12 @@ int ptmi_set_options(ptmi_ctx *c, const ptmi_options *o) {
     if (o->tile_parts > 1 && o->tile_part >= o->tile_parts)
         return fail(c, PTMI_E_INVALID, "tile_part %u is not below tile_parts %u", o->tile_part, o->tile_parts);
     if (o->perf_mode > 1) return fail(c, PTMI_E_INVALID, "unknown perf_mode %u", o->perf_mode);
-    if (o->ray_sort > 2) return fail(c, PTMI_E_INVALID, "unknown ray_sort %u", o->ray_sort);
-    if (o->overlap > 3) return fail(c, PTMI_E_INVALID, "unknown overlap %u", o->overlap);
-    if (o->worklist > 2) return fail(c, PTMI_E_INVALID, "unknown worklist %u", o->worklist);
-    if (o->tails > 2) return fail(c, PTMI_E_INVALID, "unknown tails %u", o->tails);
-    if (o->state > 2) return fail(c, PTMI_E_INVALID, "unknown state %u", o->state);
-    if (o->pipeline > 2) return fail(c, PTMI_E_INVALID, "unknown pipeline %u", o->pipeline);
+    if (o->overlap > 2) return fail(c, PTMI_E_INVALID, "unknown overlap %u", o->overlap);
+    if (o->reserved_a || o->reserved_b[0] || o->reserved_b[1] || o->reserved_b[2] || o->reserved_b[3] || o->reserved[0])
+        return fail(c, PTMI_E_INVALID, "a reserved option word is not zero (ABI <= 3's ray_sort / worklist / tails / state / pipeline are gone: "
+                    "start from ptmi_get_options)");
+    if (o->leaves > 2) return fail(c, PTMI_E_INVALID, "unknown leaves %u", o->leaves);
+    if (o->leaf_tris > PT_LEAF_MAX_TRIS) return fail(c, PTMI_E_INVALID, "leaf_tris %u above %u", o->leaf_tris, PT_LEAF_MAX_TRIS);
     if (o->tree_builder > 2) return fail(c, PTMI_E_INVALID, "unknown tree_builder %u", o->tree_builder);
     c->opt = *o;
     return PTMI_OK;
@@ -715,75 +787,49 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     // ~128 Mi paths, ~23 GB of state: the last bounces' small queues cost a fixed ~3 ms per batch, so fewer, larger batches
     // (measured at 1080p, Msamples/s: 32 frames 8 920, 64 frames 9 150 - 9 275, 128 frames 9 270 - 9 310)
     const bool auto_F = F == 0;
-    const bool state2 = (c->opt.state ? c->opt.state : (uint32_t)PT_STATE_DEFAULT) == 2u;
-    const bool want_pipe = (c->opt.pipeline ? c->opt.pipeline : (uint32_t)PT_PIPELINE_DEFAULT) == 2u && c->opt.overlap != 3;
+    Lane &ln = c->lane;
     if (auto_F) {
         F = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, (128ull << 20) / npix));
         // ... but never more than the device has room for: several contexts may share one device (ranks rehearsed on one GPU, a
         // Node host beside another process), and eight ranks of one node each size their batch by what THEIR device has free.
-        // Room = free memory + what this context's lanes already hold, less a tenth for the rest (spill areas, blit staging).
+        // Room = free memory + what this context already holds, less a tenth for the rest (spill areas, blit staging).
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            auto per_path = [](const Lane &l) { return kBytesPerPath + (l.O2 ? kBytesPerPathState2 : 0) + (l.O_b ? kBytesPerPathPipeline : 0); };
-            const uint64_t held = (uint64_t)c->lanes[0].cap * per_path(c->lanes[0]) + (uint64_t)c->lanes[1].cap * per_path(c->lanes[1]);
+            const uint64_t held = (uint64_t)ln.cap * kBytesPerPath;
             const uint64_t room = (uint64_t)((double)(free_b + held) * 0.9);
-            const uint64_t fit = room / (npix * (kBytesPerPath + (state2 ? kBytesPerPathState2 : 0) + (want_pipe ? kBytesPerPathPipeline : 0)));
-            F = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(F, fit));
+            F = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(F, room / (npix * kBytesPerPath)));
         }
     }
     F = std::min(F, n_frames);
     const bool nee = c->opt.do_mis && c->sc.n_lights > 0;
-    // overlap 1: `shadow` of bounce b on a side stream, beside extend / shade of bounce b + 1. It is then the only kernel that
+    // overlap: `shadow` of bounce b on a side stream, beside extend / shade of bounce b + 1. It is then the only kernel that
     // adds to L (emissive hits leave a record too, ShadeParams::emit_records), bounce after bounce on one stream, so every
     // path's sum is formed in the same order as without it. Record buffers alternate by bounce parity; shade(b) waits for
     // shadow(b - 2), the end of the batch for the last one.
-    // overlap 3 (not the default): additionally every batch is traced as two halves on two lanes (own buffers, own streams), the
-    // second half started when the first has compacted bounce 3 — the first half's last bounces (a tenth of the rays in queues
-    // too small for the machine) then run beside the second half's first ones, and the second half's beside the next
-    // dispatch's. `accumulate` stays on the context's stream, in frame order, after its lane's kernels. Same bits; measured
-    // 10 - 12 % SLOWER on every config (profiles/README.md): two persistent traversal grids, each sized to own every CU's LDS,
-    // take turns instead of sharing.
     const bool side = nee && c->opt.overlap != 0;
-    // tails = 2 (an experiment, measured in profiles/README.md): from bounce kTailBounce on — after the Russian roulette of pt.wgsl:699-705
-    // has thinned the queues to a tenth — `shadow` runs on the main stream behind its bounce's compaction instead of beside the next bounce
-    constexpr uint32_t kTailBounce = 4;
-    const bool serial_tail = c->opt.tails == 2 && c->opt.overlap != 3 && c->opt.max_bounces > kTailBounce;
-    bool two_lanes = c->opt.overlap == 3 && F >= 2;
-    uint32_t Fsub = two_lanes ? (F + 1) / 2 : F;                    // frames per traced batch
-    if (npix * Fsub > 0xFFFFFF00ull) return fail(c, PTMI_E_UNSUPPORTED, "batch of %llu paths exceeds 2^32", (unsigned long long)(npix * Fsub));
+    if (npix * F > 0xFFFFFF00ull) return fail(c, PTMI_E_UNSUPPORTED, "batch of %llu paths exceeds 2^32", (unsigned long long)(npix * F));
     const TraverseConfig cfg0 = traverse_config(c, true), cfg_shadow0 = traverse_config(c, false);
-    if (c->opt.traversal == PTMI_TRAVERSAL_LDS && cfg0.variant != PT_VARIANT_LDS)
+    if (c->opt.traversal == PTMI_TRAVERSAL_LDS && cfg0.variant != PT_VARIANT_LDS && cfg0.variant != PT_VARIANT_OWN_LDS && cfg0.variant != PT_VARIANT_OWN_QLDS)
         return fail(c, PTMI_E_UNSUPPORTED, "scene needs %zu B of LDS plus the stack; it does not fit in %zu B", c->lds_scene_bytes, kLdsMax);
-    if (two_lanes != c->last_two_lanes) { HIP_TRY(c, sync_all(c)); c->last_two_lanes = two_lanes; }     // lane 0 changes streams
-    // (the same when the pipeline is switched on or off: a `raygen` on the `pre` stream is only ordered against pipelined batches)
-    if ((want_pipe && !two_lanes) != c->last_pipe) { HIP_TRY(c, sync_all(c)); c->last_pipe = want_pipe && !two_lanes; }
     for (;;) {
-        rc = PTMI_OK;
-        for (int k = 0; k < (two_lanes ? 2 : 1) && rc == PTMI_OK; k++) rc = ensure_capacity(c, c->lanes[k], (size_t)(npix * Fsub), state2, want_pipe);
+        rc = ensure_capacity(c, ln, (size_t)(npix * F));
         if (rc == PTMI_OK) break;
         // out of device memory with a batch size the library chose: halve it and try again (hipMemGetInfo is a snapshot; another
         // context may have allocated since). A size the caller asked for fails loudly.
         if (!auto_F || !c->alloc_oom || F <= 1) return rc;
         F = (F + 1) / 2;
-        two_lanes = c->opt.overlap == 3 && F >= 2;
-        Fsub = two_lanes ? (F + 1) / 2 : F;
     }
-    for (int k = 0; k < (two_lanes ? 2 : 1); k++) {
-        Lane &ln = c->lanes[k];
-        if (cfg0.wants_spill && !ln.d_spill) HIP_TRY(c, hipMalloc(&ln.d_spill, pt_spill_bytes(c->n_cu * 8)));          // 128 MiB on 256 CUs
-        if (cfg_shadow0.wants_spill && !ln.d_spill_side) HIP_TRY(c, hipMalloc(&ln.d_spill_side, pt_spill_bytes(c->n_cu * 8)));
-    }
+    if (cfg0.wants_spill && !ln.d_spill) HIP_TRY(c, hipMalloc(&ln.d_spill, pt_spill_bytes(c->n_cu * 8)));          // 128 MiB on 256 CUs
+    if (cfg_shadow0.wants_spill && !ln.d_spill_side) HIP_TRY(c, hipMalloc(&ln.d_spill_side, pt_spill_bytes(c->n_cu * 8)));
 #ifndef PT_L_STRIDE
 #define PT_L_STRIDE 0              /* 0: by scene (pt_device.h, DevPaths); 3 or 4 floats: fixed */
 #endif
-    c->st.traversal_used = cfg0.variant == PT_VARIANT_GLOBAL ? PTMI_TRAVERSAL_GLOBAL : PTMI_TRAVERSAL_LDS;
-    c->st.frames_per_batch_used = Fsub;
-    c->st.worklist_used = (cfg0.worklist ? 1u : 0u) | ((nee && cfg_shadow0.worklist) ? 2u : 0u);
-    c->st.state_used = state2 ? 2u : 1u;
-    c->st.tails_used = (side && serial_tail) ? 1u : 0u;
-    const bool pipe = want_pipe && !two_lanes;
-    c->st.pipeline_used = pipe ? 2u : 1u;
-    c->st.radiance_stride_bytes = 4u * (PT_L_STRIDE ? (uint32_t)PT_L_STRIDE : ((cfg0.quantized || cfg_shadow0.quantized) ? 4u : 3u));
+    const bool from_memory = cfg0.variant == PT_VARIANT_GLOBAL || cfg0.variant == PT_VARIANT_OWN_QGLOBAL || cfg0.variant == PT_VARIANT_OWN_GLOBAL;
+    c->st.traversal_used = from_memory ? PTMI_TRAVERSAL_GLOBAL : PTMI_TRAVERSAL_LDS;
+    c->st.extend_variant = (uint32_t)cfg0.variant * 10u + (uint32_t)cfg0.wgs_per_cu;
+    c->st.shadow_variant = (uint32_t)cfg_shadow0.variant * 10u + (uint32_t)cfg_shadow0.wgs_per_cu;
+    c->st.frames_per_batch_used = F;
+    c->st.radiance_stride_bytes = 4u * (PT_L_STRIDE ? (uint32_t)PT_L_STRIDE : ((walks_memory_quantised(cfg0) || walks_memory_quantised(cfg_shadow0)) ? 4u : 3u));
     const int blocks = c->n_cu * 8;
 #ifndef PT_SHADE_WGS_PER_CU
 #define PT_SHADE_WGS_PER_CU 16
@@ -792,120 +838,55 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     // 16: 9 362, 32: 9 303, 64: 8 929 (run-to-run +-130); config 3 +-0.
     const int shade_blocks = c->n_cu * PT_SHADE_WGS_PER_CU;
     const uint32_t maxb = c->opt.max_bounces;
-    const bool sort = c->opt.ray_sort == 1;          // 2 (library default) = off: measured, profiles/README.md
     const bool t1 = c->opt.timing >= 1, t2 = c->opt.timing >= 2, t3 = c->opt.timing >= 3;
     {
         Timed td(c, 0, t1);
-        for (uint32_t f0 = 0; f0 < n_frames; f0 += Fsub) {
-            const uint32_t fb = std::min(Fsub, n_frames - f0);
+        const hipStream_t ms = c->stream;                                         // the bounce loop's stream
+        const hipStream_t ss = side ? ln.side : ms;                               // ... and the shadow kernels'
+        const int tiles = (int)(ln.cap / pt_compact_tile_slots() + 1);
+        TraverseConfig cfg = cfg0, cfg_shadow = cfg_shadow0;
+        cfg.spill = ln.d_spill; cfg_shadow.spill = side ? ln.d_spill_side : ln.d_spill;
+        if (cfg_shadow.wants_spill && !cfg_shadow.spill) cfg_shadow.spill = ln.d_spill_side;
+        ln.paths.l_stride = c->st.radiance_stride_bytes / 4u;
+        const DevPaths bp = ln.paths;
+        for (uint32_t f0 = 0; f0 < n_frames; f0 += F) {
+            const uint32_t fb = std::min(F, n_frames - f0);
             const uint32_t frame0 = cam->frame_index + f0;
-            Lane &ln = c->lanes[two_lanes ? (c->batch_seq & 1u) : 0];
-            Lane &other = c->lanes[two_lanes ? ((c->batch_seq & 1u) ^ 1u) : 0];
-            c->batch_seq++;
-            ln.paths.l_stride = c->st.radiance_stride_bytes / 4u;
-            const hipStream_t ms = two_lanes ? ln.main : c->stream;                   // where this batch's kernels go
-            const hipStream_t ss = side ? ln.side : ms;                               // ... and its shadow kernels
-            const int tiles = (int)(ln.cap / pt_compact_tile_slots() + 1);
-            TraverseConfig cfg = cfg0, cfg_shadow = cfg_shadow0;
-            cfg.spill = ln.d_spill; cfg_shadow.spill = side ? ln.d_spill_side : ln.d_spill;
-            if (cfg_shadow.wants_spill && !cfg_shadow.spill) cfg_shadow.spill = ln.d_spill_side;
-            if (two_lanes) {
-                if (ln.free_recorded) HIP_TRY(c, hipStreamWaitEvent(ms, ln.ev_free, 0));            // its buffers were folded
-                if (other.mid_recorded) HIP_TRY(c, hipStreamWaitEvent(ms, other.ev_mid, 0));        // the stagger
-            }
-            // pipeline = 2: this batch's camera rays go to the buffer set of its parity, on the lane's `pre` stream, as soon as the
-            // batch that last used that set (two batches ago) has been folded — i.e. beside the batch before this one, which is
-            // still being traced when this call enqueues; the batch's own kernels wait for them. The bounce-0 queue length that
-            // `raygen` leaves has a slot per parity too (the previous batch may still be reading its own).
-            if (pt_dynamic_claim()) HIP_TRY(c, hipMemsetAsync(ln.tickets, 0, kTickets * sizeof(uint32_t), ms));
-            const int pp = pipe ? (int)(ln.pre_seq++ & 1u) : 0;
-            DevPaths bp = ln.paths;
-            if (pp) { bp.O = ln.O_b; bp.D = ln.D_b; bp.L = ln.L_b; }
-            uint32_t *const count0 = pipe ? &ln.counts[kPipeCount + pp] : &ln.counts[0];
-            auto cnt = [&](uint32_t b) -> uint32_t * { return b == 0u ? count0 : &ln.counts[b]; };
-            if (pipe) {
-                if (ln.use_recorded[pp]) HIP_TRY(c, hipStreamWaitEvent(ln.pre, ln.ev_use[pp], 0));
-                // ... and not before the previous batch has compacted bounce 3: released at once, `raygen` would only take the
-                // machine from that batch's first bounces (measured: +-0); from bounce 4 on the queues are a tenth and the write-bound
-                // `raygen` finds idle wave slots and an idle memory system
-#ifndef PT_PIPELINE_HOLD
-#define PT_PIPELINE_HOLD 1
-#endif
-                if (PT_PIPELINE_HOLD && ln.mid_recorded) HIP_TRY(c, hipStreamWaitEvent(ln.pre, ln.ev_mid, 0));
-                { Timed t(c, 4, t3, ln.pre); pt_launch_raygen(ln.pre, blocks, *cam, band, frame0, fb, bp, count0); }
-                HIP_TRY(c, hipEventRecord(ln.ev_ray[pp], ln.pre));
-                HIP_TRY(c, hipStreamWaitEvent(ms, ln.ev_ray[pp], 0));
-            } else {
-                Timed t(c, 4, t3, ms); pt_launch_raygen(ms, blocks, *cam, band, frame0, fb, bp, count0);
-            }
+            { Timed t(c, 4, t3, ms); pt_launch_raygen(ms, blocks, *cam, band, frame0, fb, bp, &ln.counts[0]); }
             int cur = 0;
-            const uint32_t mid_bounce = std::min(3u, maxb - 1u);
-            // state = 2: the rays of bounce b live in set A (ln.paths) for b <= 1 and odd b, in set B (O2, D2, C2) for even b >= 2,
-            // at the index the queue gives: the path id up to bounce 1 (bounce 0 writes in place: its slots ARE the path ids), from
-            // then on the ray's slot in the previous bounce's queue. shade(b) reads set(b) and writes set(b + 1) at its own slots.
-            DevPaths setA = bp, setB = bp;
-            setB.O = ln.O2; setB.D = ln.D2; setB.C = ln.C2;
             for (uint32_t b = 0; b < maxb; b++) {
                 const uint32_t *q = b == 0 ? nullptr : ln.queue[cur];      // bounce 0: slot i holds path i
                 const int par = side ? (int)(b & 1u) : 0;
-                const bool in_b = state2 && b >= 2u && !(b & 1u), out_b = state2 && b >= 1u && (b & 1u);    // set B read / written
-                const DevPaths &pin = in_b ? setB : setA, &pout = out_b ? setB : setA;
-                ShadeParams shp{b, maxb, c->opt.do_mis, c->d_stats, nullptr, (uint32_t)ln.mask_words, side ? 1u : 0u,
-                                nullptr, nullptr, nullptr, nullptr, nullptr};
-                if (state2) {
-                    shp.O_out = pout.O; shp.D_out = pout.D; shp.C_out = pout.C;
-                    shp.pid_in = b >= 2u ? ln.pid[in_b ? 1 : 0] : nullptr;
-                    shp.pid_out = b >= 1u ? ln.pid[out_b ? 1 : 0] : nullptr;
-                }
-                const uint32_t *cq = state2 ? nullptr : q;                 // what compaction lists: the slots themselves / their path ids
-                cfg.ticket = ln.tickets + b; cfg_shadow.ticket = ln.tickets + 64 + b;
-                { Timed t(c, 1, t2, ms); pt_launch_extend(ms, blocks, cfg, c->sc, pin, q, cnt(b), ln.hits); }
+                const ShadeParams shp{b, maxb, c->opt.do_mis, c->d_stats, side ? 1u : 0u};
+                { Timed t(c, 1, t2, ms); (c->sc.own ? pt_launch_extend_own : pt_launch_extend)(ms, blocks, cfg, c->sc, bp, q, &ln.counts[b], ln.hits); }
                 const bool last = b + 1 == maxb;
-                uint64_t *octm = (sort && !last) ? ln.octm : nullptr;
                 if (side && b >= 2) HIP_TRY(c, hipStreamWaitEvent(ms, ln.ev_shadow[par], 0));      // its records are read
-                shp.octant_masks = octm;
                 { Timed t(c, 2, t3, ms);
                   (c->opt.perf_mode ? pt_launch_shade_fast : pt_launch_shade)(
-                      ms, shade_blocks, c->sc, pin, q, cnt(b), ln.hits, ln.sh[par], ln.alive, ln.shadowm, shp); }
+                      ms, shade_blocks, c->sc, bp, q, &ln.counts[b], ln.hits, ln.sh[par], ln.alive, ln.shadowm, shp); }
                 { Timed t(c, 5, t3, ms);
-                  pt_launch_compact(ms, tiles, cq, cnt(b), ln.alive, nee ? ln.shadowm : nullptr,
+                  pt_launch_compact(ms, tiles, q, &ln.counts[b], ln.alive, nee ? ln.shadowm : nullptr,
                                     ln.word_off, ln.queue[cur ^ 1], &ln.counts[b + 1], ln.sq[par], &ln.counts[kShadowCount + par],
-                                    c->d_stats, b, last ? 0 : 1, octm, (uint32_t)ln.mask_words); }
-                if ((two_lanes || pipe) && b == mid_bounce) { HIP_TRY(c, hipEventRecord(ln.ev_mid, ms)); ln.mid_recorded = true; }
-                if (side && serial_tail && b >= kTailBounce) {
-                    // tails = 2: the small queues of the last bounces on ONE stream, every kernel by itself. `shadow` stays the only
-                    // kernel that adds to L and keeps its bounce order: the first one here waits for the side stream's last one.
-                    if (b == kTailBounce) HIP_TRY(c, hipStreamWaitEvent(ms, ln.ev_shadow[(b - 1u) & 1u], 0));
-                    { Timed t(c, 3, t3, ms);
-                      pt_launch_shadow(ms, blocks, cfg_shadow, c->sc, bp, ln.sh[par], ln.sq[par],
-                                       &ln.counts[kShadowCount + par], nullptr); }
-                    HIP_TRY(c, hipEventRecord(ln.ev_shadow[par], ms));
-                } else if (side) {
+                                    c->d_stats, b, last ? 0 : 1); }
+                if (side) {
                     HIP_TRY(c, hipEventRecord(ln.ev_ready, ms));
                     HIP_TRY(c, hipStreamWaitEvent(ss, ln.ev_ready, 0));
                     { Timed t(c, 3, t3, ss);
-                      pt_launch_shadow(ss, blocks, cfg_shadow, c->sc, bp, ln.sh[par], ln.sq[par],
-                                       &ln.counts[kShadowCount + par], nullptr); }
+                      (c->sc.own ? pt_launch_shadow_own : pt_launch_shadow)(ss, blocks, cfg_shadow, c->sc, bp, ln.sh[par], ln.sq[par],
+                                                                            &ln.counts[kShadowCount + par], nullptr); }
                     HIP_TRY(c, hipEventRecord(ln.ev_shadow[par], ss));
                 } else if (nee) {
                     Timed t(c, 3, t3, ms);
-                    pt_launch_shadow(ms, blocks, cfg_shadow, c->sc, bp, ln.sh[0], ln.sq[0], &ln.counts[kShadowCount], nullptr);
+                    (c->sc.own ? pt_launch_shadow_own : pt_launch_shadow)(ms, blocks, cfg_shadow, c->sc, bp, ln.sh[0], ln.sq[0], &ln.counts[kShadowCount], nullptr);
                 }
                 cur ^= 1;
             }
-            // all additions to L are in before it is folded; the fold runs on the context's stream, batch after batch
-            const hipStream_t as = c->stream;
+            // all additions to L are in before it is folded
             if (side) {
-                HIP_TRY(c, hipStreamWaitEvent(two_lanes ? ms : as, ln.ev_shadow[(maxb - 1) & 1u], 0));
-                if (maxb >= 2) HIP_TRY(c, hipStreamWaitEvent(two_lanes ? ms : as, ln.ev_shadow[maxb & 1u], 0));
+                HIP_TRY(c, hipStreamWaitEvent(ms, ln.ev_shadow[(maxb - 1) & 1u], 0));
+                if (maxb >= 2) HIP_TRY(c, hipStreamWaitEvent(ms, ln.ev_shadow[maxb & 1u], 0));
             }
-            if (two_lanes) {
-                HIP_TRY(c, hipEventRecord(ln.ev_done, ms));
-                HIP_TRY(c, hipStreamWaitEvent(as, ln.ev_done, 0));
-            }
-            { Timed t(c, 6, t3, as); pt_launch_accumulate(as, blocks, band, frame0, fb, bp.L, bp.l_stride, c->d_out); }
-            if (pipe) { HIP_TRY(c, hipEventRecord(ln.ev_use[pp], as)); ln.use_recorded[pp] = true; }
-            if (two_lanes) { HIP_TRY(c, hipEventRecord(ln.ev_free, as)); ln.free_recorded = true; }
+            { Timed t(c, 6, t3, ms); pt_launch_accumulate(ms, blocks, band, frame0, fb, bp.L, bp.l_stride, c->d_out); }
         }
     }
     HIP_TRY(c, hipGetLastError());
@@ -1017,6 +998,7 @@ int ptmi_get_stats(ptmi_ctx *c, ptmi_stats *out) {
     HIP_TRY(c, hipMemcpy(h, c->d_stats, sizeof h, hipMemcpyDeviceToHost));
     c->st.segments = h[0]; c->st.shadow_rays = h[1] - h[3]; c->st.shadow_traced = h[2] - h[3];      // h[3]: records of emissive hits
     for (int i = 0; i < 64; i++) c->st.segments_by_bounce[i] = h[8 + i];
+    c->st.verify_failed = h[4];
     c->st.bvh_depth = c->bvh_depth;
     *out = c->st;
     return PTMI_OK;
@@ -1032,6 +1014,7 @@ int ptmi_reset_stats(ptmi_ctx *c) {
     std::memset(&c->st, 0, sizeof c->st);
     c->st.bvh_depth = c->bvh_depth;
     c->st.upload_ms = old.upload_ms; c->st.upload_tree_ms = old.upload_tree_ms; c->st.upload_copy_ms = old.upload_copy_ms;
+    c->st.leaves_used = old.leaves_used; c->st.leaf_tris_used = old.leaf_tris_used;
     return PTMI_OK;
 }
 
@@ -1041,9 +1024,9 @@ int ptmi_debug_raygen(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n, const uin
     if (!c || !cam || !xs || !ys || !frames || !o3 || !d3) return PTMI_E_INVALID;
     if (n == 0) return PTMI_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    Lane &ln = c->lanes[0];                          // the per-stage entry points use the first lane, on the context's stream
+    Lane &ln = c->lane;                              // the per-stage entry points run on the context's stream
     HIP_TRY(c, sync_all(c));
-    int rc = ensure_capacity(c, ln, n, false);
+    int rc = ensure_capacity(c, ln, n);
     if (rc) return rc;
     uint32_t *dx = ln.queue[0], *dy = ln.queue[1], *df = reinterpret_cast<uint32_t *>(ln.hits);
     HIP_TRY(c, hipMemcpyAsync(dx, xs, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
@@ -1069,21 +1052,20 @@ int ptmi_debug_intersect(ptmi_ctx *c, uint32_t n, const float *o3, const float *
     if (!o3 || !d3 || !t || !tri || !u || !v) return fail(c, PTMI_E_INVALID, "NULL argument");
     if (n == 0) return PTMI_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    Lane &ln = c->lanes[0];                          // the per-stage entry points use the first lane, on the context's stream
+    Lane &ln = c->lane;                              // the per-stage entry points run on the context's stream
     HIP_TRY(c, sync_all(c));
-    rc = ensure_capacity(c, ln, n, false);
+    rc = ensure_capacity(c, ln, n);
     if (rc) return rc;
     rc = upload_rays(c, n, o3, d3, nullptr, ln.paths.O, ln.paths.D);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(&ln.counts[0], &n, 4, hipMemcpyHostToDevice, c->stream));
     TraverseConfig cfg = traverse_config(c, true);
-    if (c->opt.traversal == PTMI_TRAVERSAL_LDS && cfg.variant != PT_VARIANT_LDS)
+    if (c->opt.traversal == PTMI_TRAVERSAL_LDS && cfg.variant != PT_VARIANT_LDS && cfg.variant != PT_VARIANT_OWN_LDS && cfg.variant != PT_VARIANT_OWN_QLDS)
         return fail(c, PTMI_E_UNSUPPORTED, "scene does not fit in LDS");
     if (cfg.wants_spill && !ln.d_spill) HIP_TRY(c, hipMalloc(&ln.d_spill, pt_spill_bytes(c->n_cu * 8)));
     cfg.spill = ln.d_spill;
-    if (pt_dynamic_claim()) { HIP_TRY(c, hipMemsetAsync(ln.tickets + kTickets - 1, 0, sizeof(uint32_t), c->stream)); cfg.ticket = ln.tickets + kTickets - 1; }
-    c->st.worklist_used = cfg.worklist ? 1u : 0u;
-    pt_launch_extend(c->stream, c->n_cu * 8, cfg, c->sc, ln.paths, nullptr, &ln.counts[0], ln.hits);
+    c->st.extend_variant = (uint32_t)cfg.variant * 10u + (uint32_t)cfg.wgs_per_cu;
+    (c->sc.own ? pt_launch_extend_own : pt_launch_extend)(c->stream, c->n_cu * 8, cfg, c->sc, ln.paths, nullptr, &ln.counts[0], ln.hits);
     // (u, v) are not part of the hit record: rebuilt exactly as `shade` rebuilds them (into the C stream, unused here)
     pt_launch_hit_uv(c->stream, n, c->sc, ln.paths, ln.hits, ln.paths.C);
     std::vector<float2> h(n), uv(n);
@@ -1103,9 +1085,9 @@ int ptmi_debug_occluded(ptmi_ctx *c, uint32_t n, const float *o3, const float *d
     if (!o3 || !d3 || !dist || !occ) return fail(c, PTMI_E_INVALID, "NULL argument");
     if (n == 0) return PTMI_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    Lane &ln = c->lanes[0];                          // the per-stage entry points use the first lane, on the context's stream
+    Lane &ln = c->lane;                              // the per-stage entry points run on the context's stream
     HIP_TRY(c, sync_all(c));
-    rc = ensure_capacity(c, ln, n, false);
+    rc = ensure_capacity(c, ln, n);
     if (rc) return rc;
     {   // every negative distance means "directional light" (ptmi.h). Inside the library -2 is the record of an emissive hit
         // (nothing to trace, traverse.hip ShadowIO::fetch): a caller's -2 must not be read as that, so negatives travel as -1
@@ -1118,9 +1100,8 @@ int ptmi_debug_occluded(ptmi_ctx *c, uint32_t n, const float *o3, const float *d
     TraverseConfig cfg = traverse_config(c, false);
     if (cfg.wants_spill && !ln.d_spill) HIP_TRY(c, hipMalloc(&ln.d_spill, pt_spill_bytes(c->n_cu * 8)));
     cfg.spill = ln.d_spill;
-    if (pt_dynamic_claim()) { HIP_TRY(c, hipMemsetAsync(ln.tickets + kTickets - 1, 0, sizeof(uint32_t), c->stream)); cfg.ticket = ln.tickets + kTickets - 1; }
-    c->st.worklist_used = cfg.worklist ? 2u : 0u;
-    pt_launch_shadow(c->stream, c->n_cu * 8, cfg, c->sc, ln.paths, ln.sh[0], nullptr, &ln.counts[0], ln.d_occ);
+    c->st.shadow_variant = (uint32_t)cfg.variant * 10u + (uint32_t)cfg.wgs_per_cu;
+    (c->sc.own ? pt_launch_shadow_own : pt_launch_shadow)(c->stream, c->n_cu * 8, cfg, c->sc, ln.paths, ln.sh[0], nullptr, &ln.counts[0], ln.d_occ);
     HIP_TRY(c, hipMemcpyAsync(occ, ln.d_occ, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, sync_all(c));
     HIP_TRY(c, hipGetLastError());
@@ -1132,6 +1113,7 @@ int ptmi_debug_image_stats(const ptmi_triangle *tris, uint32_t nt, const ptmi_bv
     for (int i = 0; i < 8; i++) out[i] = 0.0;
     ptmi_ctx tmp;                                   // host-only: never touches a device
     default_options(tmp.opt);
+    tmp.opt.leaves = 1;                             // the image over the reference's leaves (ptmi_debug_build_image: the own one)
     Built b;
     int rc = build_image(&tmp, tris, nt, nodes, nn, b);
     if (rc) { g_create_err = tmp.err; return rc; }
@@ -1198,6 +1180,40 @@ int ptmi_debug_image_stats(const ptmi_triangle *tris, uint32_t nt, const ptmi_bv
     }
     if (visited != b.qnodes.size() / 2) bad_hdr++;          // every node reached exactly once (a tree: no node can be reached twice)
     out[1] = (double)leaves; out[5] = viol; out[6] = boxes ? infl / (double)boxes : 0.0; out[7] = (double)bad_hdr;
+    return PTMI_OK;
+}
+
+int ptmi_debug_build_image(const ptmi_triangle *tris, uint32_t nt, const ptmi_bvh_node *nodes, uint32_t nn, const ptmi_options *opt,
+                           ptmi_image_info *info, float *wnodes16, uint32_t *qnodes8, float *tripos12, float *leafbox8) {
+    if (!info || (nt && !tris) || (nn && !nodes)) return PTMI_E_INVALID;
+    std::memset(info, 0, sizeof *info);
+    ptmi_ctx tmp;                                   // host-only: never touches a device
+    default_options(tmp.opt);
+    if (opt) { tmp.opt.leaves = opt->leaves; tmp.opt.leaf_tris = opt->leaf_tris; tmp.opt.keep_reference_tree = opt->keep_reference_tree; }
+    Built b;
+    int rc = build_image(&tmp, tris, nt, nodes, nn, b);
+    if (rc) { g_create_err = tmp.err; return rc; }
+    const bool own = b.own, fast = own || !b.fast_wnodes.empty();
+    const std::vector<float4> &walk = own ? b.own_tree.wnodes : fast ? b.fast_wnodes : b.wnodes;
+    const std::vector<float4> &tp = own ? b.own_tree.tripos : b.tripos;
+    const std::vector<uint4> &qn = own ? b.own_qnodes : b.qnodes;
+    info->leaves_used = own ? 2u : 1u;
+    info->n_wnodes = (uint32_t)(walk.size() / 4); info->n_tris = (uint32_t)(tp.size() / 3);
+    info->root_ref = own ? b.own_tree.root_ref : fast ? b.fast_root : b.root_ref;
+    info->depth = own ? b.own_tree.depth : fast ? b.fast_depth : b.depth;
+    info->n_leaves = own ? b.own_tree.n_leaves : 0u;
+    info->max_leaf_tris = own ? b.own_tree.max_leaf_tris : b.max_leaf_tris;
+    info->quantised = qn.empty() ? 0u : 1u;
+    for (int k = 0; k < 3; k++) {
+        info->root_min[k] = own ? b.own_tree.root_min[k] : b.root_min[k]; info->root_max[k] = own ? b.own_tree.root_max[k] : b.root_max[k];
+        info->q_origin[k] = b.q_origin[k]; info->q_scale[k] = b.q_scale[k];
+    }
+    info->pad = own ? b.own_tree.pad : 0.0f; info->safe_origin = own ? b.own_tree.safe_origin : 0.0f;
+    info->ref_depth = b.depth;
+    if (wnodes16 && !walk.empty()) std::memcpy(wnodes16, walk.data(), walk.size() * 16);
+    if (qnodes8 && !qn.empty()) std::memcpy(qnodes8, qn.data(), qn.size() * 16);
+    if (tripos12 && !tp.empty()) std::memcpy(tripos12, tp.data(), tp.size() * 16);
+    if (leafbox8 && !b.leafbox.empty()) std::memcpy(leafbox8, b.leafbox.data(), b.leafbox.size() * 16);
     return PTMI_OK;
 }
 

@@ -70,9 +70,12 @@ struct ptmi_multi {
     ptmi_options opt{};                                // as given by the caller (tile_strip 0 = automatic)
     uint32_t W = 0, H = 0, strip = kStripRows;
     size_t rows_max = 0;                               // rows of the largest share
+    size_t share_bytes = 0;                            // what every d_send[i] holds (d_recv: N of them): rows_max x W float4 when allocated
     std::vector<float4 *> d_send;                      // per device: its packed rows
     float4 *d_recv = nullptr;                          // device 0: N shares
     std::vector<hipEvent_t> ev;                        // loopback: device r's share is packed
+    std::vector<hipEvent_t> ev_copied;                 // loopback: device r's share has been copied out of d_send[r] (recorded on device 0's stream)
+    std::vector<char> copied_recorded;
     hipEvent_t g0 = nullptr, g1 = nullptr;             // around the last gather on device 0's stream
     bool gather_timed = false;
     uint64_t dispatched = 0, gathered = 0;             // dispatch calls so far / included in device 0's frame
@@ -116,7 +119,7 @@ void free_buffers(ptmi_multi *m) {
     for (size_t i = 0; i < m->d_send.size(); i++)
         if (m->d_send[i]) { (void)hipSetDevice(m->dev[i]); (void)hipFree(m->d_send[i]); m->d_send[i] = nullptr; }
     if (m->d_recv) { (void)hipSetDevice(m->dev[0]); (void)hipFree(m->d_recv); m->d_recv = nullptr; }
-    m->rows_max = 0;
+    m->rows_max = 0; m->share_bytes = 0;
 }
 
 // options of every context + the gather's buffers for the current size and strip height
@@ -131,11 +134,12 @@ int configure(ptmi_multi *m) {
     if (m->W == 0 || n == 1) return PTMI_OK;
     size_t rows_max = 0;
     for (int i = 0; i < n; i++) rows_max = std::max<size_t>(rows_max, pt_band_of(options_of(m, i), m->W, m->H).rows);
-    if (rows_max == m->rows_max && m->d_recv) return PTMI_OK;
+    // the buffers are sized in BYTES (rows_max x W float4): a resize that keeps the height but widens the frame needs new ones
+    const size_t share = rows_max * m->W * sizeof(float4);
+    if (rows_max == m->rows_max && share == m->share_bytes && m->d_recv) return PTMI_OK;
     int rc = ptmi_multi_synchronize(m);
     if (rc) return rc;
     free_buffers(m);
-    const size_t share = rows_max * m->W * sizeof(float4);
     for (int i = 0; i < n; i++) {
         MHIP(m, hipSetDevice(m->dev[i]));
         MHIP(m, hipMalloc(&m->d_send[i], std::max<size_t>(share, 16)));
@@ -143,7 +147,8 @@ int configure(ptmi_multi *m) {
     }
     MHIP(m, hipSetDevice(m->dev[0]));
     MHIP(m, hipMalloc(&m->d_recv, std::max<size_t>(share * n, 16)));
-    m->rows_max = rows_max;
+    m->rows_max = rows_max; m->share_bytes = share;
+    std::fill(m->copied_recorded.begin(), m->copied_recorded.end(), 0);
     return PTMI_OK;
 }
 
@@ -195,9 +200,10 @@ int ptmi_multi_create(int n, const int *ordinals, uint32_t flags, ptmi_multi **o
         }
     }
     bool ok = true;
-    m->ev.assign(n, nullptr);
+    m->ev.assign(n, nullptr); m->ev_copied.assign(n, nullptr); m->copied_recorded.assign(n, 0);
     for (int i = 0; i < n && ok; i++) {
         ok = hipSetDevice(m->dev[i]) == hipSuccess && hipEventCreateWithFlags(&m->ev[i], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipSetDevice(m->dev[0]) == hipSuccess && hipEventCreateWithFlags(&m->ev_copied[i], hipEventDisableTiming) == hipSuccess;
     }
     ok = ok && hipSetDevice(m->dev[0]) == hipSuccess && hipEventCreate(&m->g0) == hipSuccess && hipEventCreate(&m->g1) == hipSuccess;
     if (!ok) { mfail(nullptr, PTMI_E_HIP, "event creation failed"); ptmi_multi_destroy(m); return PTMI_E_HIP; }
@@ -213,6 +219,7 @@ int ptmi_multi_destroy(ptmi_multi *m) {
     for (ncclComm_t c : m->comm) if (c) (void)g_rccl.CommDestroy(c);
     free_buffers(m);
     for (size_t i = 0; i < m->ev.size(); i++) if (m->ev[i]) { (void)hipSetDevice(m->dev[i]); (void)hipEventDestroy(m->ev[i]); }
+    for (size_t i = 0; i < m->ev_copied.size(); i++) if (m->ev_copied[i]) { (void)hipSetDevice(m->dev[0]); (void)hipEventDestroy(m->ev_copied[i]); }
     if (m->g0) (void)hipEventDestroy(m->g0);
     if (m->g1) (void)hipEventDestroy(m->g1);
     for (ptmi_ctx *c : m->ctx) (void)ptmi_destroy(c);
@@ -256,6 +263,12 @@ int ptmi_multi_resize(ptmi_multi *m, uint32_t w, uint32_t h) {
 int ptmi_multi_set_options(ptmi_multi *m, const ptmi_options *o) {
     if (!m || !o) return PTMI_E_INVALID;
     if (o->tile_y0 != 0 || o->tile_y1 != 0) return mfail(m, PTMI_E_INVALID, "tile_y0 / tile_y1 must be 0: the rows are dealt out by the library");
+    // The strip height decides which device owns which rows: changing it while frames are being accumulated would hand rows that
+    // hold k frames to a device whose copy of them holds none. It takes effect with the next ptmi_multi_resize / _write_output.
+    const uint32_t new_strip = o->tile_strip ? o->tile_strip : auto_strip(m->H ? m->H : 1, (uint32_t)m->ctx.size());
+    if (m->dispatched != 0 && new_strip != m->strip)
+        return mfail(m, PTMI_E_STATE, "tile_strip %u -> %u while %llu dispatches are accumulated: call ptmi_multi_resize or ptmi_multi_write_output first",
+                     m->strip, new_strip, (unsigned long long)m->dispatched);
     const ptmi_options old = m->opt;
     m->opt = *o;
     int rc = configure(m);
@@ -286,13 +299,14 @@ int ptmi_multi_gather(ptmi_multi *m) {
     if (n == 1) {
         // one device through RCCL: the degenerate gather of its whole frame onto itself, then copied back — the frame must come
         // out of the collective unchanged (the N = 1 test of the RCCL leg on a one-GPU box)
-        if (!m->d_recv || m->rows_max != m->H) {
+        const size_t frame_bytes = (size_t)m->W * m->H * sizeof(float4);
+        if (!m->d_recv || m->rows_max != m->H || m->share_bytes != frame_bytes) {
             int rc = ptmi_multi_synchronize(m); if (rc) return rc;
             free_buffers(m);
             MHIP(m, hipSetDevice(m->dev[0]));
-            MHIP(m, hipMalloc(&m->d_send[0], (size_t)m->W * m->H * sizeof(float4)));
-            MHIP(m, hipMalloc(&m->d_recv, (size_t)m->W * m->H * sizeof(float4)));
-            m->rows_max = m->H;
+            MHIP(m, hipMalloc(&m->d_send[0], frame_bytes));
+            MHIP(m, hipMalloc(&m->d_recv, frame_bytes));
+            m->rows_max = m->H; m->share_bytes = frame_bytes;
         }
     }
     const size_t share_f4 = m->rows_max * m->W;
@@ -303,6 +317,8 @@ int ptmi_multi_gather(ptmi_multi *m) {
     for (int i = 0; i < n; i++) {
         bands[i] = pt_band_of(options_of(m, i), m->W, m->H);
         MHIP(m, hipSetDevice(m->dev[i]));
+        // loopback: the previous gather's copy out of d_send[i] (on device 0's stream) must be done before it is packed again
+        if (m->comm.empty() && i > 0 && m->copied_recorded[i]) MHIP(m, hipStreamWaitEvent(pt_ctx_stream(m->ctx[i]), m->ev_copied[i], 0));
         if (bands[i].rows) pt_launch_pack_rows(pt_ctx_stream(m->ctx[i]), pt_ctx_cus(m->ctx[i]) * 8, bands[i], pt_ctx_output(m->ctx[i]), m->d_send[i]);
     }
     if (!m->comm.empty()) {
@@ -320,6 +336,8 @@ int ptmi_multi_gather(ptmi_multi *m) {
             MHIP(m, hipSetDevice(m->dev[0]));
             MHIP(m, hipStreamWaitEvent(s0, m->ev[i], 0));
             MHIP(m, hipMemcpyPeerAsync(m->d_recv + (size_t)i * share_f4, m->dev[0], m->d_send[i], m->dev[i], share_f4 * sizeof(float4), s0));
+            MHIP(m, hipEventRecord(m->ev_copied[i], s0));
+            m->copied_recorded[i] = 1;
         }
     }
     MHIP(m, hipSetDevice(m->dev[0]));
@@ -371,7 +389,7 @@ int ptmi_multi_write_output(ptmi_multi *m, const float *src, size_t n_floats) {
         int rc = ptmi_write_output(m->ctx[i], src, n_floats);
         if (rc) return cfail(m, (int)i, rc, "ptmi_write_output");
     }
-    m->gathered = m->dispatched;
+    m->dispatched = m->gathered = 0;          // every device holds the whole frame again: the rows may be dealt out anew
     return PTMI_OK;
 }
 
@@ -399,6 +417,7 @@ int ptmi_multi_get_stats(ptmi_multi *m, ptmi_stats *out) {
         sum.raygen_ms = std::max(sum.raygen_ms, s.raygen_ms); sum.compact_ms = std::max(sum.compact_ms, s.compact_ms);
         sum.accumulate_ms = std::max(sum.accumulate_ms, s.accumulate_ms);
         sum.upload_ms = std::max(sum.upload_ms, s.upload_ms);
+        sum.verify_failed += s.verify_failed;
     }
     *out = sum;
     return PTMI_OK;

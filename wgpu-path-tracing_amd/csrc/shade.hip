@@ -301,13 +301,12 @@ __global__ __launch_bounds__(SBLOCK) PT_SHADE_ATTR void k_shade(DevScene sc, Dev
     for (uint32_t base = blockIdx.x * SBLOCK; base < count; base += gridDim.x * SBLOCK) {
         const uint32_t i = base + threadIdx.x;
         bool alive = false, shadow = false, skipped = false, emitted = false;
-        bool neg_x = false, neg_y = false, neg_z = false;          // ray_sort: octant of the new direction
         if (i < count) {
             const uint32_t q = queue ? queue[i] : i;                         // where this ray's state is
             const float2 h2 = ld_stream(&hits[i]);
             if (!(h2.x < 0.0f)) {                                            // pt.wgsl:646: miss adds zero
                 const float4 o4 = ld_stream(&P.O[q]), d4 = ld_stream(&P.D[q]);
-                const uint32_t p = sp.pid_in ? sp.pid_in[q] : q;             // the path (its radiance); q itself while the state is in place
+                const uint32_t p = q;                                            // the path id: where its radiance is
                 uint32_t rng = __float_as_uint(o4.w);
                 const v3 ro = xyz(o4), rd = xyz(d4);
                 v3 thr = mk3(1.0f, 1.0f, 1.0f);                                      // pt.wgsl:639; raygen stores no throughput
@@ -365,17 +364,9 @@ __global__ __launch_bounds__(SBLOCK) PT_SHADE_ATTR void k_shade(DevScene sc, Dev
                             else thr = vdiv3(thr, pr);
                         }
                         if (alive && sp.bounce + 1u < sp.max_bounces) {
-                            neg_x = nd.x < 0.0f; neg_y = nd.y < 0.0f; neg_z = nd.z < 0.0f;
-                            if (sp.O_out) {                                   // the state follows the queue (pt_device.h ShadeParams)
-                                st_stream(&sp.O_out[i], make_float4(no.x, no.y, no.z, __uint_as_float(rng)));
-                                st_stream(&sp.D_out[i], make_float4(nd.x, nd.y, nd.z, thr.x));
-                                st_stream(&sp.C_out[i], make_float2(thr.y, thr.z));
-                                if (sp.pid_out) sp.pid_out[i] = p;
-                            } else {
-                                st_stream(&P.O[q], make_float4(no.x, no.y, no.z, __uint_as_float(rng)));
-                                st_stream(&P.D[q], make_float4(nd.x, nd.y, nd.z, thr.x));
-                                st_stream(&P.C[q], make_float2(thr.y, thr.z));
-                            }
+                            st_stream(&P.O[q], make_float4(no.x, no.y, no.z, __uint_as_float(rng)));
+                            st_stream(&P.D[q], make_float4(nd.x, nd.y, nd.z, thr.x));
+                            st_stream(&P.C[q], make_float2(thr.y, thr.z));
                         }
                     }
                 }
@@ -386,7 +377,7 @@ __global__ __launch_bounds__(SBLOCK) PT_SHADE_ATTR void k_shade(DevScene sc, Dev
                 const float tx = reinterpret_cast<const float *>(&P.D[q])[3];
                 const float2 c2 = ld_stream(&P.C[q]);
                 if (!(__builtin_isfinite(tx) & __builtin_isfinite(c2.x) & __builtin_isfinite(c2.y))) {
-                    const uint32_t p = sp.pid_in ? sp.pid_in[q] : q;
+                    const uint32_t p = q;
                     const v3 e = mk3(tx * 0.0f, c2.x * 0.0f, c2.y * 0.0f);
                     if (sp.emit_records) {
                         st_stream(&S.SO[i], make_float4(0.0f, 0.0f, 0.0f, -2.0f));
@@ -406,14 +397,6 @@ __global__ __launch_bounds__(SBLOCK) PT_SHADE_ATTR void k_shade(DevScene sc, Dev
             shadow_mask[i >> 6] = sm;
             n_skipped += (uint32_t)__popcll(zm);
             n_emitted += (uint32_t)__popcll(em);
-        }
-        if (sp.octant_masks) {
-            const uint64_t bx = __ballot(neg_x), by = __ballot(neg_y), bz = __ballot(neg_z);
-            if ((threadIdx.x & 63u) == 0u && i < count) {
-                sp.octant_masks[i >> 6] = bx;
-                sp.octant_masks[sp.octant_stride + (i >> 6)] = by;
-                sp.octant_masks[2u * sp.octant_stride + (i >> 6)] = bz;
-            }
         }
     }
     if (n_skipped) atomicAdd(&sp.stats[1], (unsigned long long)n_skipped);

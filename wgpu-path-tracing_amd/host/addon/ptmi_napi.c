@@ -163,13 +163,10 @@ static void read_options(napi_env env, napi_value obj, ptmi_options *o) {
     o->tile_part = get_u32_prop(env, obj, "tilePart", o->tile_part);
     o->tile_strip = get_u32_prop(env, obj, "tileStrip", o->tile_strip);
     o->perf_mode = get_u32_prop(env, obj, "perfMode", o->perf_mode);
-    o->ray_sort = get_u32_prop(env, obj, "raySort", o->ray_sort);
     o->overlap = get_u32_prop(env, obj, "overlap", o->overlap);
-    o->worklist = get_u32_prop(env, obj, "worklist", o->worklist);
-    o->tails = get_u32_prop(env, obj, "tails", o->tails);
-    o->state = get_u32_prop(env, obj, "state", o->state);
-    o->pipeline = get_u32_prop(env, obj, "pipeline", o->pipeline);
     o->tree_builder = get_u32_prop(env, obj, "treeBuilder", o->tree_builder);
+    o->leaves = get_u32_prop(env, obj, "leaves", o->leaves);
+    o->leaf_tris = get_u32_prop(env, obj, "leafTris", o->leaf_tris);
 }
 
 static napi_value js_set_options(napi_env env, napi_callback_info info) {
@@ -290,7 +287,9 @@ static napi_value stats_object(napi_env env, const ptmi_stats *s) {
     set_num(env, o, "shadowTraced", (double)s->shadow_traced); set_num(env, o, "uploadMs", s->upload_ms);
     set_num(env, o, "bvhDepth", s->bvh_depth); set_num(env, o, "traversalUsed", s->traversal_used);
     set_num(env, o, "framesPerBatchUsed", s->frames_per_batch_used);
-    set_num(env, o, "worklistUsed", s->worklist_used); set_num(env, o, "stateUsed", s->state_used);
+    set_num(env, o, "leavesUsed", s->leaves_used); set_num(env, o, "leafTrisUsed", s->leaf_tris_used);
+    set_num(env, o, "extendVariant", s->extend_variant); set_num(env, o, "shadowVariant", s->shadow_variant);
+    set_num(env, o, "verifyFailed", (double)s->verify_failed);
     return o;
 }
 

@@ -26,25 +26,21 @@ export interface TraceOptions {
   tileParts?: number; tilePart?: number; tileStrip?: number;
   /** include/ptmi.h: 1 = fast reciprocal / sqrt in `shade` (statistically, not bitwise, the same image); never the default */
   perfMode?: 0 | 1;
-  /** 0 / 1 / 2 (library default): group each 1024-slot window of the ray queue by direction octant */
-  raySort?: 0 | 1 | 2;
   /** 0 / 1 / 2 (library default): run the shadow kernel on a second stream beside the next bounce */
-  overlap?: 0 | 1 | 2 | 3;
-  /** 0 (library default) / 1 off / 2 on: triangle tests of the LDS traversal kernels through a per-wave work list */
-  worklist?: 0 | 1 | 2;
-  /** 0 (library default) / 1 every kernel its own launch / 2 shadow(b) and extend(b + 1) in one traversal launch */
-  tails?: 0 | 1 | 2;
-  /** 0 (library default) / 1 ray state in place by path id / 2 the state follows the queue (denser gathers in late bounces) */
-  state?: 0 | 1 | 2;
-  /** 0 (library default) / 1 off / 2 the next batch's camera rays are generated on their own stream beside this batch's last bounces */
-  pipeline?: 0 | 1 | 2;
+  overlap?: 0 | 1 | 2;
   /** read at loadModel: 0 (library default) / 1 the host builds the traversal hierarchy (SAH) / 2 the GPU does (linear BVH) */
   treeBuilder?: 0 | 1 | 2;
+  /** read at loadModel: 0 (library default = 2) / 1 triangles are tested in the uploaded BVH's own leaves / 2 in the library's own
+   *  leaves (a SAH hierarchy over the triangles; the winner is verified against its reference leaf, results unchanged) */
+  leaves?: 0 | 1 | 2;
+  /** leaves = 2: most triangles per own leaf (0 = library default) */
+  leafTris?: number;
 }
 export interface Stats {
   paths: number; segments: number; shadowRays: number; frames: number; dispatches: number;
   gpuMs: number; extendMs: number; shadeMs: number; shadowMs: number; bvhDepth: number; traversalUsed: number;
-  shadowTraced: number; uploadMs: number; framesPerBatchUsed: number; worklistUsed: number; stateUsed: number;
+  shadowTraced: number; uploadMs: number; framesPerBatchUsed: number; leavesUsed: number; leafTrisUsed: number;
+  extendVariant: number; shadowVariant: number; verifyFailed: number;
 }
 export class Renderer {
   constructor(options?: { device?: number; width?: number; height?: number; options?: TraceOptions });

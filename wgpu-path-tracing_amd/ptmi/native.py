@@ -22,14 +22,14 @@ EXPORTS = [
     "ptmi_synchronize", "ptmi_read_output", "ptmi_write_output", "ptmi_output_device_ptr",
     "ptmi_bind_output_device", "ptmi_set_stream", "ptmi_blit", "ptmi_get_stats", "ptmi_reset_stats",
     "ptmi_debug_raygen", "ptmi_debug_intersect", "ptmi_debug_occluded", "ptmi_debug_math", "ptmi_debug_exact_math", "ptmi_get_size",
-    "ptmi_debug_image_stats", "ptmi_throttle", "ptmi_multi_throttle",
+    "ptmi_debug_image_stats", "ptmi_debug_build_image", "ptmi_throttle", "ptmi_multi_throttle",
     "ptmi_multi_create", "ptmi_multi_destroy", "ptmi_multi_last_error", "ptmi_multi_count", "ptmi_multi_context",
     "ptmi_multi_upload_scene", "ptmi_multi_upload_atlas", "ptmi_multi_resize", "ptmi_multi_set_options", "ptmi_multi_get_options",
     "ptmi_multi_dispatch", "ptmi_multi_gather", "ptmi_multi_synchronize", "ptmi_multi_read_output", "ptmi_multi_write_output",
     "ptmi_multi_blit", "ptmi_multi_get_stats", "ptmi_multi_reset_stats", "ptmi_multi_gather_ms",
 ]
 MULTI_LOOPBACK = 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class PtmiError(RuntimeError):
@@ -44,9 +44,9 @@ class Options(ctypes.Structure):
                 ("frames_per_batch", ctypes.c_uint32), ("traversal", ctypes.c_uint32),
                 ("cull", ctypes.c_uint32), ("timing", ctypes.c_uint32), ("keep_reference_tree", ctypes.c_uint32),
                 ("tile_parts", ctypes.c_uint32), ("tile_part", ctypes.c_uint32), ("tile_strip", ctypes.c_uint32),
-                ("perf_mode", ctypes.c_uint32), ("ray_sort", ctypes.c_uint32), ("overlap", ctypes.c_uint32),
-                ("worklist", ctypes.c_uint32), ("tails", ctypes.c_uint32), ("state", ctypes.c_uint32),
-                ("pipeline", ctypes.c_uint32), ("tree_builder", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 3)]
+                ("perf_mode", ctypes.c_uint32), ("reserved_a", ctypes.c_uint32), ("overlap", ctypes.c_uint32),
+                ("reserved_b", ctypes.c_uint32 * 4), ("tree_builder", ctypes.c_uint32),
+                ("leaves", ctypes.c_uint32), ("leaf_tris", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 1)]
 
 
 class Stats(ctypes.Structure):
@@ -60,11 +60,11 @@ class Stats(ctypes.Structure):
                 ("shadow_traced", ctypes.c_uint64), ("shade_launches", ctypes.c_uint64), ("shadow_launches", ctypes.c_uint64),
                 ("raygen_ms", ctypes.c_double), ("compact_ms", ctypes.c_double), ("accumulate_ms", ctypes.c_double),
                 ("upload_ms", ctypes.c_double), ("upload_tree_ms", ctypes.c_double), ("upload_copy_ms", ctypes.c_double),
-                ("worklist_used", ctypes.c_uint32), ("tails_used", ctypes.c_uint32),
-                ("state_used", ctypes.c_uint32), ("pipeline_used", ctypes.c_uint32)]
+                ("leaves_used", ctypes.c_uint32), ("leaf_tris_used", ctypes.c_uint32),
+                ("extend_variant", ctypes.c_uint32), ("shadow_variant", ctypes.c_uint32), ("verify_failed", ctypes.c_uint64)]
 
     def as_dict(self):
-        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("segments_by_bounce", "reserved", "reserved_stats")}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("segments_by_bounce",)}
         d["segments_by_bounce"] = [int(v) for v in self.segments_by_bounce if v]
         return d
 
@@ -102,6 +102,7 @@ def load():
         L.ptmi_blit.argtypes = [vp, vp, sz, vp, sz]
         L.ptmi_get_size.argtypes = [vp, vp, vp]
         L.ptmi_debug_image_stats.argtypes = [vp, u32, vp, u32, vp]
+        L.ptmi_debug_build_image.argtypes = [vp, u32, vp, u32, vp, vp, vp, vp, vp, vp]
         if L.ptmi_abi_version() != ABI_VERSION:
             raise PtmiError(-1, f"{LIB_PATH} has ABI {L.ptmi_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
         L.ptmi_get_stats.argtypes = [vp, vp]
@@ -150,6 +151,36 @@ def image_stats(scene):
     keys = ("wide_nodes", "leaves", "depth", "quantised_nodes", "stream_dwords", "containment_violations",
             "mean_area_growth", "stream_mismatches")
     return dict(zip(keys, list(out)))
+
+
+class ImageInfo(ctypes.Structure):
+    _fields_ = [("leaves_used", ctypes.c_uint32), ("n_wnodes", ctypes.c_uint32), ("n_tris", ctypes.c_uint32),
+                ("root_ref", ctypes.c_uint32), ("depth", ctypes.c_uint32), ("n_leaves", ctypes.c_uint32),
+                ("max_leaf_tris", ctypes.c_uint32), ("quantised", ctypes.c_uint32),
+                ("root_min", ctypes.c_float * 3), ("root_max", ctypes.c_float * 3),
+                ("pad", ctypes.c_float), ("safe_origin", ctypes.c_float),
+                ("q_origin", ctypes.c_float * 3), ("q_scale", ctypes.c_float * 3), ("ref_depth", ctypes.c_uint32)]
+
+
+def build_image(scene, leaves=0, leaf_tris=0, keep_reference_tree=0):
+    """Host-only: the traversal image ptmi_upload_scene would build (include/ptmi.h: ptmi_debug_build_image), as numpy arrays:
+    (info, wnodes [n, 16] f32, qnodes [n, 8] u32 or None, tripos [m, 12] f32, leafbox [n_triangles, 8] f32 or None)."""
+    L = load()
+    o = Options()
+    o.leaves, o.leaf_tris, o.keep_reference_tree = leaves, leaf_tris, keep_reference_tree
+    info = ImageInfo()
+    args = (_p(scene.tris), len(scene.tris), _p(scene.nodes), len(scene.nodes), ctypes.byref(o), ctypes.byref(info))
+    rc = L.ptmi_debug_build_image(*args, None, None, None, None)
+    if rc != 0:
+        raise PtmiError(rc, L.ptmi_last_error(None).decode())
+    wn = np.zeros((info.n_wnodes, 16), np.float32)
+    qn = np.zeros((info.n_wnodes, 8), np.uint32) if info.quantised else None
+    tp = np.zeros((info.n_tris, 12), np.float32)
+    lb = np.zeros((len(scene.tris), 8), np.float32) if info.leaves_used == 2 else None
+    rc = L.ptmi_debug_build_image(*args, _p(wn), _p(qn), _p(tp), _p(lb))
+    if rc != 0:
+        raise PtmiError(rc, L.ptmi_last_error(None).decode())
+    return info, wn, qn, tp, lb
 
 
 class Context:
