@@ -211,6 +211,102 @@ def cpu_baseline(scene, cam_kw, width, height, bounces, mis, threads, target_s=1
     }
 
 
+def single_process(args, cfg, overridden, steps, fps, spp):
+    """--single-process: N devices driven by ONE process through ptmi_multi_* — the reference's own model (one host thread, one
+    Renderer: src/renderer/renderer.ts:415-454). Same sharding (interleaved strips), the library's own pack -> ncclGather -> unpack
+    inside the timed region, the same JSON line (per-kernel times are the maximum over the devices). With --rehearse every "device"
+    is GPU 0 and device-to-device copies stand in for the collective (PTMI_MULTI_LOOPBACK): the packing, not a benchmark."""
+    import numpy as np
+    from ptmi import layout, native, scenes, shard
+    n = args.gpus
+    strong = cfg["scaling"] == "strong"
+    W, H = (cfg["width"], cfg["height"]) if strong else shard.weak_frame(cfg["width"], cfg["height"], n)
+    cam_kw = dict(aperture=cfg["aperture"], focus_distance=cfg["focus"])
+    scene = scenes.make(cfg["scene"])
+    m = native.MultiContext([0] * n if args.rehearse else list(range(n)), loopback=bool(args.rehearse))
+    upload_opts = {}
+    for k, v in (("tree_builder", args.tree_builder), ("leaves", args.leaves), ("leaf_tris", args.leaf_tris)):
+        if v is not None:
+            upload_opts[k] = v
+    if upload_opts:
+        m.set_options(**upload_opts)
+    t_up = time.perf_counter()
+    m.upload_scene(scene)
+    upload_wall_ms = (time.perf_counter() - t_up) * 1e3
+    m.resize(W, H)
+    trav = {"auto": native.TRAVERSAL_AUTO, "global": native.TRAVERSAL_GLOBAL, "lds": native.TRAVERSAL_LDS,
+            "global_exact": native.TRAVERSAL_GLOBAL_EXACT}[args.traversal]
+    m.set_options(max_bounces=cfg["bounces"], do_mis=cfg["mis"], frames_per_batch=args.frames_per_batch, traversal=trav, cull=1, timing=args.timing,
+                  **({"overlap": args.overlap} if args.overlap is not None else {}))
+    frame_index = 0
+    enqueue_ms = []
+
+    def step():
+        nonlocal frame_index
+        t = time.perf_counter()
+        m.dispatch(layout.make_camera(W, H, frame_index=frame_index, **cam_kw), fps)
+        enqueue_ms.append((time.perf_counter() - t) * 1e3)      # host time of enqueuing N devices from one thread
+        frame_index += fps
+
+    for _ in range(args.warmup):
+        step()
+    m.gather()
+    m.synchronize()
+    m.reset_stats()
+    enqueue_ms.clear()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    m.gather()
+    m.synchronize()
+    dt = time.perf_counter() - t0
+    st = m.stats()
+    ok = None
+    if args.rehearse:                # the gathered frame against one device's unsharded render of the same frames
+        got = m.read_output()
+        with native.Context(0) as c:
+            c.upload_scene(scene)
+            c.resize(W, H)
+            c.set_options(max_bounces=cfg["bounces"], do_mis=cfg["mis"])
+            for k in range(args.warmup + steps):
+                c.dispatch(layout.make_camera(W, H, frame_index=k * fps, **cam_kw), fps)
+            ok = bool(np.array_equal(got.view(np.uint32), c.read_output().view(np.uint32)))
+    segments, paths = float(st.segments), float(st.paths)
+    msamples = segments / dt / 1e6
+    out = {
+        "metric": "Msamples/s (rays x bounces / s)", "value": round(msamples, 3), "unit": "Msamples/s",
+        "n_gpus": n, "steps": steps, "warmup": args.warmup, "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True,
+        "scaling": cfg["scaling"], "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE.json {cfg['name']}: {cfg['scene']} "
+                        + (f"{W}x{H} frame split over {n} GPU(s)" if strong else f"{cfg['width']}x{cfg['height']} pixels per GPU (frame {W}x{H})")
+                        + f", {spp} spp, {cfg['bounces']} bounces, MIS {'on' if cfg['mis'] else 'off'}, aperture {cfg['aperture']:g}, focus {cfg['focus']:g}"
+                        + (f"; overridden: {','.join(overridden)}" if overridden else ""),
+            "config_index": args.config, "frames_per_step": fps, "frames_per_batch": int(st.frames_per_batch_used),
+            "driver": "one process, ptmi_multi_* (one host thread, one stream per device, ncclGather behind the C ABI)",
+            "parallelism": f"{int(m.options().tile_strip)}-row strips x{n}", "leaves": int(st.leaves_used),
+            "extend_variant": int(st.extend_variant), "shadow_variant": int(st.shadow_variant),
+        },
+        **({"rehearsal": {"sharded_equals_unsharded_bitwise": ok, "backend": "loopback copies on one GPU", "note": "not a benchmark"}} if args.rehearse else {}),
+        "segments": int(segments), "shadow_rays": int(st.shadow_rays), "paths": int(paths), "mean_path_length": round(segments / max(paths, 1), 4),
+        "gpu_ms_max_over_devices": round(st.gpu_ms, 3),
+        "kernel_ms_max_over_devices": {"extend": round(st.extend_ms, 3), "shade": round(st.shade_ms, 3), "shadow": round(st.shadow_ms, 3),
+                                       "raygen": round(st.raygen_ms, 3), "compact": round(st.compact_ms, 3), "accumulate": round(st.accumulate_ms, 3)},
+        "gather_ms": round(m.gather_ms(), 4),
+        # one thread enqueues every device's kernels in turn: device i starts this much after device 0 (the launch skew of a step)
+        "enqueue_ms_per_step": {"mean": round(float(np.mean(enqueue_ms)), 3), "max": round(float(np.max(enqueue_ms)), 3),
+                                "per_device_mean": round(float(np.mean(enqueue_ms)) / n, 3)},
+        "upload_ms": {"wall_all_devices": round(upload_wall_ms, 2), "library_max": round(st.upload_ms, 2)},
+        "roofline": {"bound": "hbm", "kernel": "pipeline (whole dispatch)", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "achieved": round(msamples * 1e6 * pipeline_bytes_per_segment(cfg["mis"], segments / max(paths, 1), int(st.radiance_stride_bytes) or 12) / 1e9, 3),
+                     "frac": round(msamples * 1e6 * pipeline_bytes_per_segment(cfg["mis"], segments / max(paths, 1), int(st.radiance_stride_bytes) or 12) / 1e9 / HBM_PEAK_GBS, 6),
+                     "traffic": None},
+    }
+    print(json.dumps(out), flush=True)
+    m.close()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))

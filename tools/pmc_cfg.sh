@@ -17,7 +17,7 @@ import json
 d=json.load(open('$out/summary.json'))
 ks=sorted({k for c in d.values() if isinstance(c,dict) for k in c})
 for k in ks:
-    if not ('trace' in k or 'shade' in k): continue
+    if not ('trace' in k or 'own' in k or 'shade' in k): continue
     g=lambda c: d.get(c,{}).get(k,{}).get('avg_per_launch')
     a,t,v,s=g('SQ_ACTIVE_INST_VALU'),g('SQ_THREAD_CYCLES_VALU'),g('SQ_INSTS_VALU'),g('SQ_INSTS_SALU')
     line=f"{k:24s}"

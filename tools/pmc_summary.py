@@ -25,7 +25,7 @@ def to_json(paths, commit=None):
             if not m:
                 continue
             k = m.group(1)
-            if k.startswith('k_trace'):
+            if k.startswith(('k_trace', 'k_own')):
                 k += '/shadow' if 'ShadowIO' in name else '/extend'
             a = acc[(r['Counter_Name'], k)]
             a[0] += 1

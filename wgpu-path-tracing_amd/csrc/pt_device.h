@@ -23,6 +23,7 @@
 #define PT_LEAF_OFF_BITS 26u
 #define PT_LEAF_OFF_MASK ((1u << PT_LEAF_OFF_BITS) - 1u)
 
+struct DevScene;
 struct DevScene {
     const ptmi_triangle *tris;  uint32_t n_tris;
     const ptmi_material *mats;  uint32_t n_mats;
@@ -55,6 +56,7 @@ struct DevScene {
     float ref_root_min[3], ref_root_max[3];
     float safe_origin;          // |o|_inf up to which the boxes' padding covers the rounding of the fused slab test
     unsigned long long *verify_stat;    // += rays whose winner failed its reference leaf's box and were traced again
+    const DevScene *self;       // this description in device memory (the own-leaf kernels read it from there, not from kernel arguments)
 };
 
 // ---- path state: 56 B per path, four streams indexed by path id ----
@@ -170,6 +172,11 @@ struct ptmi_options;
 DevBand pt_band_of(const ptmi_options &opt, uint32_t width, uint32_t height);
 // what ptmi_multi.hip needs from a context (ptmi_api.hip)
 struct ptmi_ctx;
+struct PtPrepared;               // a scene prepared on the host: validation + traversal image (ptmi_api.hip)
+PtPrepared *pt_prepare_scene(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_material *mats, uint32_t nm,
+                             const ptmi_bvh_node *nodes, uint32_t nn, const ptmi_light *lights, uint32_t nl, int *rc_out);
+int pt_install_scene(ptmi_ctx *c, const PtPrepared *p);      // allocates and copies on c's device; c keeps its old scene on failure
+void pt_free_prepared(PtPrepared *p);
 hipStream_t pt_ctx_stream(ptmi_ctx *c);
 float4 *pt_ctx_output(ptmi_ctx *c);
 int pt_ctx_device(const ptmi_ctx *c);

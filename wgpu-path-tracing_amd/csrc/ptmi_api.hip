@@ -55,7 +55,8 @@ struct ptmi_ctx {
     // scene (bindings 1, 2, 4, 5, 6)
     void *d_tris = nullptr, *d_mats = nullptr, *d_lights = nullptr, *d_atlas = nullptr;
     float4 *d_wnodes = nullptr, *d_tripos = nullptr, *d_fast_wnodes = nullptr;
-    float4 *d_own_tripos = nullptr, *d_leafbox = nullptr;               // own leaves: leaf-ordered triangle images, per-triangle reference leaf boxes
+    float4 *d_own_tripos = nullptr, *d_leafbox = nullptr;
+    DevScene *d_scene = nullptr;                       // sc in device memory (DevScene::self), rewritten whenever sc changes               // own leaves: leaf-ordered triangle images, per-triangle reference leaf boxes
     uint4 *d_qnodes = nullptr; uint32_t *d_leaf_stream = nullptr;        // quantised image of the rebuilt hierarchy (global variant)
     DevScene sc{};
     uint32_t bvh_depth = 0;
@@ -597,6 +598,7 @@ int ptmi_create(int device_ordinal, ptmi_ctx **out) {
         if (!ok) { ptmi_destroy(c); return fail(nullptr, PTMI_E_HIP, "stream / event creation failed"); }
     }
     if (hipMalloc(&c->d_stats, kStatsWords * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(&c->d_scene, sizeof(DevScene)) != hipSuccess || hipMemset(c->d_scene, 0, sizeof(DevScene)) != hipSuccess ||
         hipMemset(c->d_stats, 0, kStatsWords * sizeof(unsigned long long)) != hipSuccess) {
         ptmi_destroy(c); return fail(nullptr, PTMI_E_HIP, "device allocation failed");
     }
@@ -620,31 +622,59 @@ int ptmi_destroy(ptmi_ctx *c) {
     }
     dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_atlas); dfree(c->d_wnodes); dfree(c->d_tripos);
     dfree(c->d_fast_wnodes); dfree(c->d_qnodes); dfree(c->d_leaf_stream); dfree(c->d_own_tripos); dfree(c->d_leafbox);
-    dfree(c->d_out_own); dfree(c->d_stats); dfree(c->d_blit_f32); dfree(c->d_blit_u8);
+    dfree(c->d_out_own); dfree(c->d_stats); dfree(c->d_scene); dfree(c->d_blit_f32); dfree(c->d_blit_u8);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return PTMI_OK;
 }
 
-int ptmi_upload_scene(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_material *mats, uint32_t nm,
-                      const ptmi_bvh_node *nodes, uint32_t nn, const ptmi_light *lights, uint32_t nl) {
-    if (!c) return PTMI_E_INVALID;
+}  // extern "C"
+
+// A scene prepared on the host (validation + traversal image: everything of an upload that does not depend on the device), and the
+// caller's blobs it was made from. ptmi_upload_scene = prepare + install; ptmi_multi_upload_scene prepares ONCE and installs on N devices.
+struct PtPrepared {
+    Built b;
+    const ptmi_triangle *tris; uint32_t nt; const ptmi_material *mats; uint32_t nm;
+    const ptmi_light *lights; uint32_t nl;
+    double build_ms;
+    ptmi_options opt;                        // what it was built under (leaves, leaf_tris, keep_reference_tree, tree_builder)
+};
+
+PtPrepared *pt_prepare_scene(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_material *mats, uint32_t nm,
+                             const ptmi_bvh_node *nodes, uint32_t nn, const ptmi_light *lights, uint32_t nl, int *rc_out) {
+    auto bad = [&](int rc) -> PtPrepared * { *rc_out = rc; return nullptr; };
+    if (!c) return bad(PTMI_E_INVALID);
     if ((nt && !tris) || (nm && !mats) || (nn && !nodes) || (nl && !lights))
-        return fail(c, PTMI_E_INVALID, "NULL blob with a non-zero count");
-    HIP_TRY(c, hipSetDevice(c->device));
+        return bad(fail(c, PTMI_E_INVALID, "NULL blob with a non-zero count"));
+    if (hipSetDevice(c->device) != hipSuccess) return bad(fail(c, PTMI_E_HIP, "hipSetDevice(%d) failed", c->device));
     for (uint32_t i = 0; i < nl; i++) {
         if (lights[i].light_type > PTMI_LIGHT_POINT)
-            return fail(c, PTMI_E_INVALID, "light %u has unknown type %u", i, lights[i].light_type);
+            return bad(fail(c, PTMI_E_INVALID, "light %u has unknown type %u", i, lights[i].light_type));
         if (lights[i].light_type == PTMI_LIGHT_EMISSIVE && lights[i].triangle_index >= nt)
-            return fail(c, PTMI_E_INVALID, "emissive light %u references triangle %u of %u", i, lights[i].triangle_index, nt);
+            return bad(fail(c, PTMI_E_INVALID, "emissive light %u references triangle %u of %u", i, lights[i].triangle_index, nt));
     }
+    const auto t_start = std::chrono::steady_clock::now();
+    PtPrepared *p = new PtPrepared();
+    int rc = build_image(c, tris, nt, nodes, nn, p->b);
+    if (rc) { delete p; return bad(rc); }
+    p->tris = tris; p->nt = nt; p->mats = mats; p->nm = nm; p->lights = lights; p->nl = nl;
+    p->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    p->opt = c->opt;
+    *rc_out = PTMI_OK;
+    return p;
+}
+void pt_free_prepared(PtPrepared *p) { delete p; }
+
+int pt_install_scene(ptmi_ctx *c, const PtPrepared *prep) {
+    if (!c || !prep) return PTMI_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
     using clk = std::chrono::steady_clock;
     auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     const auto t_start = clk::now();
-    Built b;
-    int rc = build_image(c, tris, nt, nodes, nn, b);
-    if (rc) return rc;
-    const double build_ms = ms_since(t_start);
+    const Built &b = prep->b;
+    const ptmi_triangle *tris = prep->tris; const uint32_t nt = prep->nt;
+    const ptmi_material *mats = prep->mats; const uint32_t nm = prep->nm;
+    const ptmi_light *lights = prep->lights; const uint32_t nl = prep->nl;
     // Allocate and fill the new buffers first; the context keeps its previous scene until all of them exist.
     const auto t_copy = clk::now();
     void *n_tris = nullptr, *n_mats = nullptr, *n_lights = nullptr;
@@ -706,6 +736,8 @@ int ptmi_upload_scene(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const
     s.tri_leafbox = c->d_leafbox;
     s.safe_origin = own ? b.own_tree.safe_origin : 0.0f;
     s.verify_stat = c->d_stats + 4;
+    s.self = c->d_scene;
+    HIP_TRY(c, hipMemcpy(c->d_scene, &c->sc, sizeof(DevScene), hipMemcpyHostToDevice));
     c->bvh_depth = std::max(b.depth, b.fast_depth);           // stacks must hold either tree (irregular rays use the uploaded one)
     c->own_depth = own ? b.own_tree.depth : 0u;
     c->own_quant = own && quant;
@@ -715,9 +747,20 @@ int ptmi_upload_scene(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const
     c->st.leaf_tris_used = own ? b.own_tree.max_leaf_tris : b.max_leaf_tris;
     c->st.upload_copy_ms = ms_since(t_copy);
     c->st.upload_tree_ms = b.tree_ms;
-    c->st.upload_ms = ms_since(t_start);
-    (void)build_ms;
+    c->st.upload_ms = prep->build_ms + ms_since(t_start);
     return PTMI_OK;
+}
+
+extern "C" {
+
+int ptmi_upload_scene(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_material *mats, uint32_t nm,
+                      const ptmi_bvh_node *nodes, uint32_t nn, const ptmi_light *lights, uint32_t nl) {
+    int rc = PTMI_OK;
+    PtPrepared *p = pt_prepare_scene(c, tris, nt, mats, nm, nodes, nn, lights, nl, &rc);
+    if (!p) return rc;
+    rc = pt_install_scene(c, p);
+    pt_free_prepared(p);
+    return rc;
 }
 
 int ptmi_upload_atlas(ptmi_ctx *c, const void *texels, uint32_t w, uint32_t h, int fmt) {
@@ -732,6 +775,7 @@ int ptmi_upload_atlas(ptmi_ctx *c, const void *texels, uint32_t w, uint32_t h, i
     HIP_TRY(c, hipMalloc(&c->d_atlas, bytes));
     HIP_TRY(c, hipMemcpy(c->d_atlas, texels, bytes, hipMemcpyHostToDevice));
     c->sc.atlas = c->d_atlas; c->sc.atlas_w = w; c->sc.atlas_h = h; c->sc.atlas_fmt = (uint32_t)fmt;
+    HIP_TRY(c, hipMemcpy(c->d_scene, &c->sc, sizeof(DevScene), hipMemcpyHostToDevice));
     return PTMI_OK;
 }
 

@@ -233,11 +233,17 @@ ptmi_ctx *ptmi_multi_context(ptmi_multi *m, int i) { return (m && i >= 0 && i < 
 int ptmi_multi_upload_scene(ptmi_multi *m, const ptmi_triangle *tris, uint32_t nt, const ptmi_material *mats, uint32_t nm,
                             const ptmi_bvh_node *nodes, uint32_t nn, const ptmi_light *lights, uint32_t nl) {
     if (!m) return PTMI_E_INVALID;
-    for (size_t i = 0; i < m->ctx.size(); i++) {
-        int rc = ptmi_upload_scene(m->ctx[i], tris, nt, mats, nm, nodes, nn, lights, nl);
-        if (rc) return cfail(m, (int)i, rc, "ptmi_upload_scene");
+    // validation, the hierarchy and its images are built ONCE on the host (under device 0's options: all devices share them) and copied
+    // to every device — the 1 M-triangle scene costs one build, not N (round 3: N x 196 ms)
+    int rc = PTMI_OK;
+    PtPrepared *p = pt_prepare_scene(m->ctx[0], tris, nt, mats, nm, nodes, nn, lights, nl, &rc);
+    if (!p) return cfail(m, 0, rc, "ptmi_upload_scene (prepare)");
+    for (size_t i = 0; i < m->ctx.size() && rc == PTMI_OK; i++) {
+        rc = pt_install_scene(m->ctx[i], p);
+        if (rc) rc = cfail(m, (int)i, rc, "ptmi_upload_scene (install)");
     }
-    return PTMI_OK;
+    pt_free_prepared(p);
+    return rc;
 }
 
 int ptmi_multi_upload_atlas(ptmi_multi *m, const void *texels, uint32_t w, uint32_t h, int fmt) {

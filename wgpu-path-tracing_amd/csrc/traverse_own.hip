@@ -342,9 +342,15 @@ constexpr int GBLOCK = 256, LBLOCK = 1024;
 
 // LAYOUT: 0 exact nodes (64 B) in LDS, 1 quantised nodes (32 B) in LDS. TRIS: the triangle images in LDS too.
 // Dynamic LDS: [nodes][triangles][STACK x 1024 entries]
+// (STACK = 15 is the footprint of two workgroups per CU: 8 waves per SIMD, which the register allocator has to be told — at most 64
+// vector registers; left alone the max-ILP scheduler takes 72)
 template <int MODE, bool CULL, int STACK, int LAYOUT, bool TRIS, bool SPILL, class IO>
-__global__ __launch_bounds__(LBLOCK) PT_OWN_LDS_ATTR void k_own_lds(DevScene sc, IO io, const uint32_t *__restrict__ count_ptr,
+__global__ __launch_bounds__(LBLOCK) __attribute__((amdgpu_waves_per_eu(STACK == 15 ? 8 : 4))) PT_OWN_LDS_ATTR void k_own_lds(const DevScene *__restrict__ scp, IO io, const uint32_t *__restrict__ count_ptr,
                                                                     uint32_t *__restrict__ spill) {
+    // The scene description is read from memory where it is needed (the root boxes and limits at a refill, the uploaded tree by slow
+    // rays, the leaf-box table at a verification) instead of living in scalar registers for the whole kernel: passed by value the
+    // kernel took 104 of them, and two 1024-thread workgroups share a CU only up to 80 (traverse.hip: ShadowIO).
+    const DevScene &sc = *scp;
     extern __shared__ float4 smem[];
     const uint32_t count = *count_ptr;
     if (blockIdx.x * 64u >= count) return;      // wave 0 owns group blockIdx.x; if that is empty the whole group is idle
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(LBLOCK) PT_OWN_LDS_ATTR void k_own_lds(DevScene sc,
 }
 
 template <int MODE, bool CULL, int STACK, int LAYOUT, bool TRIS, bool SPILL, class IO>
-void launch_own_lds(hipStream_t s, int wgs, size_t bytes, const DevScene &sc, const IO &io, const uint32_t *count, uint32_t *spill) {
+void launch_own_lds(hipStream_t s, int wgs, size_t bytes, const DevScene *sc, const IO &io, const uint32_t *count, uint32_t *spill) {
     static std::atomic<uint64_t> raised{0};      // the default dynamic-LDS cap is 64 KB; raise it once per instantiation and device
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -383,7 +389,8 @@ void launch_own_lds(hipStream_t s, int wgs, size_t bytes, const DevScene &sc, co
 
 // from global memory: 256-thread workgroups, 16 LDS entries per lane + the spill area; QUANT: quantised nodes, the top of the tree in LDS
 template <int MODE, bool CULL, bool QUANT, class IO>
-__global__ __launch_bounds__(GBLOCK) void k_own_global(DevScene sc, IO io, const uint32_t *__restrict__ count_ptr, uint32_t *__restrict__ spill) {
+__global__ __launch_bounds__(GBLOCK) void k_own_global(const DevScene *__restrict__ scp, IO io, const uint32_t *__restrict__ count_ptr, uint32_t *__restrict__ spill) {
+    const DevScene &sc = *scp;
     __shared__ uint32_t stk[16 * GBLOCK];
     const uint32_t count = *count_ptr;
     const uint32_t gw = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(GBLOCK) void k_own_global(DevScene sc, IO io, const
 }
 constexpr int GLOBAL_WGS_MAX = 8;          // what the spill area is sized for (traverse.hip pt_spill_bytes)
 template <int MODE, bool CULL, bool QUANT, class IO>
-void launch_own_global(hipStream_t s, int cus, const DevScene &sc, const IO &io, const uint32_t *count, uint32_t *spill) {
+void launch_own_global(hipStream_t s, int cus, const DevScene *sc, const IO &io, const uint32_t *count, uint32_t *spill) {
     static int per_cu = 0;                   // the persistent grid is exactly the workgroups that are resident at once (traverse.hip)
     if (per_cu == 0) {
         int n = 0;
@@ -417,10 +424,11 @@ void launch_own_global(hipStream_t s, int cus, const DevScene &sc, const IO &io,
 }
 
 template <int MODE, bool CULL, class IO>
-void launch_own(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, const IO &io, const uint32_t *count) {
+void launch_own(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &hsc, const IO &io, const uint32_t *count) {
     const int cus = blocks / 8 > 0 ? blocks / 8 : 1;
-    const size_t node_bytes = (size_t)sc.n_wnodes * (cfg.variant == PT_VARIANT_OWN_LDS || cfg.variant == PT_VARIANT_OWN_LDS_NODES ? 64 : 32);
-    const size_t tri_bytes = (size_t)sc.n_own_tris * 48;
+    const DevScene *sc = hsc.self;              // the kernels read the description from device memory
+    const size_t node_bytes = (size_t)hsc.n_wnodes * (cfg.variant == PT_VARIANT_OWN_LDS || cfg.variant == PT_VARIANT_OWN_LDS_NODES ? 64 : 32);
+    const size_t tri_bytes = (size_t)hsc.n_own_tris * 48;
     const size_t stack_bytes = (size_t)cfg.stack_entries * LBLOCK * sizeof(uint32_t);
     switch (cfg.variant) {
     case PT_VARIANT_OWN_LDS:                    // exact nodes + triangles resident, one workgroup per CU
