@@ -331,6 +331,7 @@ def main():
     ap.add_argument("--leaves", type=int, default=None,
                     help="library option leaves, read at upload (1: the uploaded BVH's leaves; 2: the library's own leaves; default: the library's)")
     ap.add_argument("--leaf-tris", type=int, default=None, help="library option leaf_tris (most triangles per own leaf)")
+    ap.add_argument("--shade-sort", type=int, default=None, help="library option shade_sort (1: off, 2: segments dealt to the lanes by the kind of hit)")
     ap.add_argument("--no-leaves-compare", action="store_true",
                     help="skip the second timed leg (N = 1 only) that renders the same steps with the OTHER leaf mode for `leaves_compare`")
     ap.add_argument("--single-process", action="store_true",
@@ -430,6 +431,8 @@ def main():
         extra["perf_mode"] = args.perf_mode
     if args.overlap is not None:
         extra["overlap"] = args.overlap
+    if args.shade_sort is not None:
+        extra["shade_sort"] = args.shade_sort
     ctx.set_options(max_bounces=cfg["bounces"], do_mis=mis, frames_per_batch=args.frames_per_batch, traversal=trav, cull=1,
                     timing=args.timing, **extra, **shard.strip_options(world, rank, strip))
 
@@ -524,7 +527,8 @@ def main():
         # same view), so they apply whatever --steps / --warmup are; any flag that changes the dispatch itself rules them out
         is_profiled = (not overridden and world == 1 and args.traversal == "auto"
                        and not args.perf_mode and args.overlap is None and not args.keep_reference_tree
-                       and args.frames_per_batch == 0 and args.tree_builder is None and args.leaves is None and args.leaf_tris is None)
+                       and args.frames_per_batch == 0 and args.tree_builder is None and args.leaves is None and args.leaf_tris is None
+                       and args.shade_sort is None)
         traffic, traffic_src = pmc_traffic(args.config, is_profiled)
 
         def kernel_entry(label, name, ms, launches, units, bytes_per_unit):
@@ -574,7 +578,7 @@ def main():
                 "triangles": int(len(scene.tris)), "bvh_nodes": int(len(scene.nodes)), "parallelism": par,
                 **({"perf_mode": args.perf_mode} if args.perf_mode else {}),
                 "leaves": int(st.leaves_used), "leaf_tris": int(st.leaf_tris_used),
-                "extend_variant": int(st.extend_variant), "shadow_variant": int(st.shadow_variant),
+                "extend_variant": int(st.extend_variant), "shadow_variant": int(st.shadow_variant), "shade_sort": int(st.shade_sort_used),
             },
             "verify_failed_rank0": int(st.verify_failed),
             **({"leaves_compare": leaves_compare} if leaves_compare else {}),

@@ -97,7 +97,10 @@ typedef struct ptmi_options {
                                        traced again over the uploaded tree, so results equal mode 1's;
                                    0 = library default (2) */
     uint32_t leaf_tris;         /* leaves = 2: most triangles per own leaf, 1 .. 32; 0 = library default (measured: profiles/README.md) */
-    uint32_t reserved[1];
+    uint32_t shade_sort;        /* 1 = `shade` takes the segments of a queue in slot order; 2 = from bounce 1 on each workgroup deals the 256
+                                   segments of a round to its lanes by the kind of hit (miss / emissive / transmissive / metallic / diffuse
+                                   material), so that a wave runs one branch of pt.wgsl:646-705 instead of all of them. Every segment is
+                                   computed by the same operations and written to its own slot: same results. 0 = library default */
 } ptmi_options;
 
 typedef struct ptmi_stats {
@@ -132,6 +135,8 @@ typedef struct ptmi_stats {
     /* leaves = 2: closest hits / occluders whose reference leaf's box did not pass and rays that were therefore traced again over the
      * uploaded tree (both kernels together), since the last reset */
     uint64_t verify_failed;
+    uint32_t shade_sort_used;   /* 1 / 2: ptmi_options.shade_sort as the last dispatch ran */
+    uint32_t reserved_stats;
 } ptmi_stats;
 
 /* ---- lifetime ----------------------------------------------------------- */

@@ -421,3 +421,29 @@ def test_interleaved_strips_cover_the_frame(gpu_ctx, oracle, scene_factory, part
     with pytest.raises(Exception):
         gpu_ctx.set_options(tile_parts=2, tile_part=2)
     gpu_ctx.set_options(tile_y0=0, tile_y1=0, tile_parts=0, tile_part=0, tile_strip=0)
+
+
+@pytest.mark.parametrize("name", ["cornell", "cornell_glass", "feature_box", "cornell_spheres"])
+def test_shade_sort_is_invisible(gpu_ctx, oracle, scene_factory, name):
+    """shade_sort = 2: from bounce 1 on every workgroup of `shade` deals the 256 segments of a round to its lanes by the kind of hit
+    (miss / emissive / transmissive / metallic / diffuse material) — other lanes, same segments, results written to the segment's own
+    slot, ballot words rebuilt in slot order. The image and the counters must not move by a bit: 200x130 pixels x 5 frames (queues
+    that end inside a 256-slot round), several batches per dispatch, 1 / 2 / 8 bounces, both streams modes (pt.wgsl:646-705)."""
+    sc = scene_factory(name)
+    W, H, frames = 200, 130, 5
+    cam = layout.make_camera(W, H, aperture=0.02, focus_distance=2.8)
+    gpu_ctx.upload_scene(sc)
+    for bounces in (8, 2, 1):
+        ref, ost = oracle.render(sc, cam, frames, max_bounces=bounces, do_mis=1)
+        for sort, fpb, overlap in ((2, 0, 1), (2, 2, 1), (2, 0, 0), (1, 0, 1)):
+            gpu_ctx.resize(W, H)
+            gpu_ctx.set_options(max_bounces=bounces, do_mis=1, tile_y0=0, tile_y1=0, tile_parts=0, frames_per_batch=fpb, cull=1, traversal=0,
+                                shade_sort=sort, overlap=overlap)
+            gpu_ctx.reset_stats()
+            gpu_ctx.dispatch(cam, frames)
+            got = gpu_ctx.read_output()
+            st = gpu_ctx.stats()
+            assert st.shade_sort_used == sort
+            assert (st.segments, st.shadow_rays, st.paths) == (ost.segments, ost.shadow_rays, ost.paths)
+            assert_same_floats(got, ref, f"radiance ({name}, shade_sort {sort}, frames_per_batch {fpb}, overlap {overlap}, {bounces} bounces)")
+    gpu_ctx.set_options(shade_sort=0, frames_per_batch=0, overlap=2, max_bounces=8)

@@ -56,6 +56,7 @@ struct DevScene {
     float ref_root_min[3], ref_root_max[3];
     float safe_origin;          // |o|_inf up to which the boxes' padding covers the rounding of the fused slab test
     unsigned long long *verify_stat;    // += rays whose winner failed its reference leaf's box and were traced again
+    const uint8_t *tri_class;   // per triangle: the kind of its material (shade.hip: the key `shade` sorts a workgroup's segments by); NULL: none
     const DevScene *self;       // this description in device memory (the own-leaf kernels read it from there, not from kernel arguments)
 };
 
@@ -104,6 +105,7 @@ struct DevBand {
 struct ShadeParams {
     uint32_t bounce, max_bounces, do_mis;
     unsigned long long *stats;          // [1] += next-event samples counted but not traced (zero contribution)
+    uint32_t sort;                      // 1: the segments of a workgroup round are dealt to the lanes by the kind of hit (shade.hip k_shade<SORT>)
     uint32_t emit_records;              // 1: an emissive hit does not add to L here; it leaves a record (SO.w = -2: nothing to trace)
                                         //    that `shadow` adds like an unoccluded light sample — all additions to L then happen in
                                         //    that one kernel, in bounce order, and `shadow` can run beside the next bounce's kernels.

@@ -56,6 +56,7 @@ struct ptmi_ctx {
     void *d_tris = nullptr, *d_mats = nullptr, *d_lights = nullptr, *d_atlas = nullptr;
     float4 *d_wnodes = nullptr, *d_tripos = nullptr, *d_fast_wnodes = nullptr;
     float4 *d_own_tripos = nullptr, *d_leafbox = nullptr;
+    uint8_t *d_tri_class = nullptr;
     DevScene *d_scene = nullptr;                       // sc in device memory (DevScene::self), rewritten whenever sc changes               // own leaves: leaf-ordered triangle images, per-triangle reference leaf boxes
     uint4 *d_qnodes = nullptr; uint32_t *d_leaf_stream = nullptr;        // quantised image of the rebuilt hierarchy (global variant)
     DevScene sc{};
@@ -234,6 +235,7 @@ struct Built {
     PtOwnTree own_tree;
     std::vector<uint4> own_qnodes;           // quantised nodes of own_tree (empty: a 16-bit grid does not resolve this scene)
     std::vector<float4> leafbox;             // 2 float4 per triangle (original index): its reference leaf's box
+    std::vector<uint8_t> tri_class;          // per triangle: kind of its material (shade.hip N_CLASSES: 1 emissive, 2 transmissive, 3 metallic, 4 diffuse)
 };
 
 #ifndef PT_LEAVES_DEFAULT
@@ -621,7 +623,7 @@ int ptmi_destroy(ptmi_ctx *c) {
         if (ln.side) (void)hipStreamDestroy(ln.side);
     }
     dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_atlas); dfree(c->d_wnodes); dfree(c->d_tripos);
-    dfree(c->d_fast_wnodes); dfree(c->d_qnodes); dfree(c->d_leaf_stream); dfree(c->d_own_tripos); dfree(c->d_leafbox);
+    dfree(c->d_fast_wnodes); dfree(c->d_qnodes); dfree(c->d_leaf_stream); dfree(c->d_own_tripos); dfree(c->d_leafbox); dfree(c->d_tri_class);
     dfree(c->d_out_own); dfree(c->d_stats); dfree(c->d_scene); dfree(c->d_blit_f32); dfree(c->d_blit_u8);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -658,6 +660,18 @@ PtPrepared *pt_prepare_scene(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt
     int rc = build_image(c, tris, nt, nodes, nn, p->b);
     if (rc) { delete p; return bad(rc); }
     p->tris = tris; p->nt = nt; p->mats = mats; p->nm = nm; p->lights = lights; p->nl = nl;
+    p->b.tri_class.resize(nt);
+    for (uint32_t i = 0; i < nt; i++) {              // the key `shade` sorts by: which branch of pt.wgsl:646-705 a hit on this triangle takes
+        const uint32_t mi = tris[i].material_index;
+        uint8_t k = 4;
+        if (mi < nm) {
+            const ptmi_material &m = mats[mi];
+            if (m.emission[0] > 0.0f || m.emission[1] > 0.0f || m.emission[2] > 0.0f) k = 1;
+            else if (m.transmission > 0.0f) k = 2;
+            else if (m.metallic >= 0.5f) k = 3;
+        }
+        p->b.tri_class[i] = k;
+    }
     p->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
     p->opt = c->opt;
     *rc_out = PTMI_OK;
@@ -679,7 +693,7 @@ int pt_install_scene(ptmi_ctx *c, const PtPrepared *prep) {
     const auto t_copy = clk::now();
     void *n_tris = nullptr, *n_mats = nullptr, *n_lights = nullptr;
     float4 *n_wnodes = nullptr, *n_tripos = nullptr, *n_fast = nullptr, *n_own_tripos = nullptr, *n_leafbox = nullptr;
-    uint4 *n_qnodes = nullptr; uint32_t *n_stream = nullptr;
+    uint4 *n_qnodes = nullptr; uint32_t *n_stream = nullptr; uint8_t *n_class = nullptr;
     const bool own = b.own;
     const std::vector<uint4> &qn = own ? b.own_qnodes : b.qnodes;
     const bool quant = !qn.empty();
@@ -699,16 +713,18 @@ int pt_install_scene(ptmi_ctx *c, const PtPrepared *prep) {
     if (e == hipSuccess && fast) e = up(reinterpret_cast<void **>(&n_fast), walk.data(), walk.size() * 16);
     if (e == hipSuccess && own) e = up(reinterpret_cast<void **>(&n_own_tripos), b.own_tree.tripos.data(), b.own_tree.tripos.size() * 16);
     if (e == hipSuccess && own) e = up(reinterpret_cast<void **>(&n_leafbox), b.leafbox.data(), b.leafbox.size() * 16);
+    if (e == hipSuccess) e = up(reinterpret_cast<void **>(&n_class), b.tri_class.data(), b.tri_class.size());
     if (e == hipSuccess && quant) e = up(reinterpret_cast<void **>(&n_qnodes), qn.data(), qn.size() * 16);
     if (e == hipSuccess && quant && !own) e = up(reinterpret_cast<void **>(&n_stream), b.leaf_stream.data(), b.leaf_stream.size() * 4);
     if (e != hipSuccess) {
         dfree(n_tris); dfree(n_mats); dfree(n_lights); dfree(n_wnodes); dfree(n_tripos); dfree(n_fast); dfree(n_qnodes); dfree(n_stream);
-        dfree(n_own_tripos); dfree(n_leafbox);
+        dfree(n_own_tripos); dfree(n_leafbox); dfree(n_class);
         return fail(c, PTMI_E_HIP, "scene upload failed: %s (the previous scene, if any, is still in place)", hipGetErrorString(e));
     }
     HIP_TRY(c, sync_all(c));                  // nothing in flight reads the old buffers any more
     dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_wnodes); dfree(c->d_tripos); dfree(c->d_fast_wnodes);
-    dfree(c->d_qnodes); dfree(c->d_leaf_stream); dfree(c->d_own_tripos); dfree(c->d_leafbox);
+    dfree(c->d_qnodes); dfree(c->d_leaf_stream); dfree(c->d_own_tripos); dfree(c->d_leafbox); dfree(c->d_tri_class);
+    c->d_tri_class = n_class;
     c->d_qnodes = n_qnodes; c->d_leaf_stream = n_stream;
     c->d_tris = n_tris; c->d_mats = n_mats; c->d_lights = n_lights;
     c->d_wnodes = n_wnodes; c->d_tripos = n_tripos; c->d_fast_wnodes = n_fast;
@@ -734,6 +750,7 @@ int pt_install_scene(ptmi_ctx *c, const PtPrepared *prep) {
     s.own = own ? 1u : 0u;
     s.n_own_tris = own ? (uint32_t)(b.own_tree.tripos.size() / 3) : 0u;
     s.tri_leafbox = c->d_leafbox;
+    s.tri_class = c->d_tri_class;
     s.safe_origin = own ? b.own_tree.safe_origin : 0.0f;
     s.verify_stat = c->d_stats + 4;
     s.self = c->d_scene;
@@ -801,9 +818,10 @@ int ptmi_set_options(ptmi_ctx *c, const ptmi_options *o) {
         return fail(c, PTMI_E_INVALID, "tile_part %u is not below tile_parts %u", o->tile_part, o->tile_parts);
     if (o->perf_mode > 1) return fail(c, PTMI_E_INVALID, "unknown perf_mode %u", o->perf_mode);
     if (o->overlap > 2) return fail(c, PTMI_E_INVALID, "unknown overlap %u", o->overlap);
-    if (o->reserved_a || o->reserved_b[0] || o->reserved_b[1] || o->reserved_b[2] || o->reserved_b[3] || o->reserved[0])
+    if (o->reserved_a || o->reserved_b[0] || o->reserved_b[1] || o->reserved_b[2] || o->reserved_b[3])
         return fail(c, PTMI_E_INVALID, "a reserved option word is not zero (ABI <= 3's ray_sort / worklist / tails / state / pipeline are gone: "
                     "start from ptmi_get_options)");
+    if (o->shade_sort > 2) return fail(c, PTMI_E_INVALID, "unknown shade_sort %u", o->shade_sort);
     if (o->leaves > 2) return fail(c, PTMI_E_INVALID, "unknown leaves %u", o->leaves);
     if (o->leaf_tris > PT_LEAF_MAX_TRIS) return fail(c, PTMI_E_INVALID, "leaf_tris %u above %u", o->leaf_tris, PT_LEAF_MAX_TRIS);
     if (o->tree_builder > 2) return fail(c, PTMI_E_INVALID, "unknown tree_builder %u", o->tree_builder);
@@ -882,6 +900,11 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     // 16: 9 362, 32: 9 303, 64: 8 929 (run-to-run +-130); config 3 +-0.
     const int shade_blocks = c->n_cu * PT_SHADE_WGS_PER_CU;
     const uint32_t maxb = c->opt.max_bounces;
+#ifndef PT_SHADE_SORT_DEFAULT
+#define PT_SHADE_SORT_DEFAULT 1        /* what ptmi_options.shade_sort = 0 means: 1 off, 2 on (measured: profiles/README.md) */
+#endif
+    const bool shade_sort = (c->opt.shade_sort ? c->opt.shade_sort : (uint32_t)PT_SHADE_SORT_DEFAULT) == 2u;
+    c->st.shade_sort_used = shade_sort ? 2u : 1u;
     const bool t1 = c->opt.timing >= 1, t2 = c->opt.timing >= 2, t3 = c->opt.timing >= 3;
     {
         Timed td(c, 0, t1);
@@ -901,7 +924,8 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
             for (uint32_t b = 0; b < maxb; b++) {
                 const uint32_t *q = b == 0 ? nullptr : ln.queue[cur];      // bounce 0: slot i holds path i
                 const int par = side ? (int)(b & 1u) : 0;
-                const ShadeParams shp{b, maxb, c->opt.do_mis, c->d_stats, side ? 1u : 0u};
+                // (bounce 0 is coherent by itself: camera rays of one wave hit one material)
+                const ShadeParams shp{b, maxb, c->opt.do_mis, c->d_stats, (shade_sort && b >= 1u) ? 1u : 0u, side ? 1u : 0u};
                 { Timed t(c, 1, t2, ms); (c->sc.own ? pt_launch_extend_own : pt_launch_extend)(ms, blocks, cfg, c->sc, bp, q, &ln.counts[b], ln.hits); }
                 const bool last = b + 1 == maxb;
                 if (side && b >= 2) HIP_TRY(c, hipStreamWaitEvent(ms, ln.ev_shadow[par], 0));      // its records are read

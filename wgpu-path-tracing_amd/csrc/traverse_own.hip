@@ -330,6 +330,10 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
 
 // ------------------------------------------------------------------ kernels ----
 constexpr int GBLOCK = 256, LBLOCK = 1024;
+// refill when at most this many of the 64 lanes still hold a ray (scene in LDS; traverse_common.h has the value of the other kernels)
+#ifndef PT_OWN_REFILL_AT
+#define PT_OWN_REFILL_AT PT_REFILL_AT
+#endif
 
 #ifndef PT_OWN_LDS_WAVES
 #define PT_OWN_LDS_WAVES 0
@@ -366,10 +370,10 @@ __global__ __launch_bounds__(LBLOCK) __attribute__((amdgpu_waves_per_eu(STACK ==
     if constexpr (LAYOUT == 1) {
         OwnQuantMem<true, TRIS> m{(lds_u4p)smem, (glb_u4p)sc.qnodes, sc.n_wnodes, (lds_f4p)(smem + nw), (glb_f4p)sc.tripos,
                                   sc.q_origin[0], sc.q_origin[1], sc.q_origin[2], sc.q_scale[0], sc.q_scale[1], sc.q_scale[2]};
-        trace_wave_own<MODE, CULL, STACK, SPILL, REFILL_AT>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk, LBLOCK, sp, gridDim.x * LBLOCK);
+        trace_wave_own<MODE, CULL, STACK, SPILL, PT_OWN_REFILL_AT>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk, LBLOCK, sp, gridDim.x * LBLOCK);
     } else {
         OwnLdsMem<TRIS> m{(lds_f4p)smem, (lds_f4p)(smem + nw), (glb_f4p)sc.tripos};
-        trace_wave_own<MODE, CULL, STACK, SPILL, REFILL_AT>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk, LBLOCK, sp, gridDim.x * LBLOCK);
+        trace_wave_own<MODE, CULL, STACK, SPILL, PT_OWN_REFILL_AT>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk, LBLOCK, sp, gridDim.x * LBLOCK);
     }
 }
 

@@ -46,7 +46,7 @@ class Options(ctypes.Structure):
                 ("tile_parts", ctypes.c_uint32), ("tile_part", ctypes.c_uint32), ("tile_strip", ctypes.c_uint32),
                 ("perf_mode", ctypes.c_uint32), ("reserved_a", ctypes.c_uint32), ("overlap", ctypes.c_uint32),
                 ("reserved_b", ctypes.c_uint32 * 4), ("tree_builder", ctypes.c_uint32),
-                ("leaves", ctypes.c_uint32), ("leaf_tris", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 1)]
+                ("leaves", ctypes.c_uint32), ("leaf_tris", ctypes.c_uint32), ("shade_sort", ctypes.c_uint32)]
 
 
 class Stats(ctypes.Structure):
@@ -61,7 +61,8 @@ class Stats(ctypes.Structure):
                 ("raygen_ms", ctypes.c_double), ("compact_ms", ctypes.c_double), ("accumulate_ms", ctypes.c_double),
                 ("upload_ms", ctypes.c_double), ("upload_tree_ms", ctypes.c_double), ("upload_copy_ms", ctypes.c_double),
                 ("leaves_used", ctypes.c_uint32), ("leaf_tris_used", ctypes.c_uint32),
-                ("extend_variant", ctypes.c_uint32), ("shadow_variant", ctypes.c_uint32), ("verify_failed", ctypes.c_uint64)]
+                ("extend_variant", ctypes.c_uint32), ("shadow_variant", ctypes.c_uint32), ("verify_failed", ctypes.c_uint64),
+                ("shade_sort_used", ctypes.c_uint32), ("reserved_stats", ctypes.c_uint32)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("segments_by_bounce",)}
