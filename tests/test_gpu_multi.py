@@ -90,3 +90,59 @@ def test_multi_errors_are_loud():
             m.set_options(tile_y0=2, tile_y1=9)
         with pytest.raises(native.PtmiError):
             m.dispatch(layout.make_camera(8, 8), 1)             # no scene yet
+
+
+def test_resize_to_a_wider_frame_of_the_same_height_reallocates_the_gather_buffers(oracle, scene_factory):
+    """the gather's send / receive buffers hold rows_max x W float4 — a resize that keeps the height and widens the
+    frame (a horizontal window resize through Renderer.resize) must not keep the smaller ones. 64x48 -> 128x48 on one handle, three
+    loopback shards and one device through RCCL; the second frame against the oracle."""
+    from ptmi import native
+    sc = scene_factory("cornell")
+    for devices, loop in (([0, 0, 0], True), ([0], False)):
+        with native.MultiContext(devices, loopback=loop) as m:
+            m.upload_scene(sc)
+            for W, H in ((64, 48), (128, 48), (40, 48)):
+                cam = layout.make_camera(W, H)
+                m.resize(W, H)
+                m.set_options(max_bounces=8, do_mis=1)
+                m.dispatch(cam, 2)
+                m.gather()
+                got = m.read_output()
+                ref, _ = oracle.render(sc, cam, 2, max_bounces=8, do_mis=1)
+                assert_same_floats(got, ref, f"{W}x{H} after a resize ({len(devices)} shard(s))")
+
+
+def test_strip_height_cannot_change_while_frames_are_accumulated(scene_factory):
+    from ptmi import native
+    sc = scene_factory("cornell")
+    with native.MultiContext([0, 0], loopback=True) as m:
+        m.upload_scene(sc)
+        m.resize(64, 48)
+        m.set_options(max_bounces=4, do_mis=1, tile_strip=4)
+        m.dispatch(layout.make_camera(64, 48), 1)
+        with pytest.raises(native.PtmiError):
+            m.set_options(tile_strip=2)                         # would hand rows that hold a frame to a device that holds none of them
+        m.write_output(np.zeros((48, 64, 4), np.float32))       # every device holds the whole frame again
+        m.set_options(tile_strip=2)
+
+
+def test_two_devices_over_rccl_assemble_the_oracle_frame(oracle, scene_factory):
+    """The real N > 1 path: ncclCommInitAll over two devices, one grouped ncclGather with a NULL receive buffer on the non-root,
+    unpack of slot 1. Skipped on a one-GPU box (every box this suite has run on so far): the first multi-GPU node runs it."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (N > 1 over RCCL has never run from the build container)")
+    from ptmi import native
+    sc = scene_factory("cornell")
+    W, H, frames = 96, 70, 3
+    cam = layout.make_camera(W, H)
+    ref, ost = oracle.render(sc, cam, frames, max_bounces=8, do_mis=1)
+    with native.MultiContext([0, 1]) as m:
+        m.upload_scene(sc)
+        m.resize(W, H)
+        m.set_options(max_bounces=8, do_mis=1)
+        m.dispatch(cam, frames)
+        got = m.read_output()
+        st = m.stats()
+    assert (st.segments, st.shadow_rays, st.paths) == (ost.segments, ost.shadow_rays, ost.paths)
+    assert_same_floats(got, ref, "frame gathered from two devices over RCCL")
