@@ -334,6 +334,8 @@ def main():
     ap.add_argument("--shade-sort", type=int, default=None, help="library option shade_sort (1: off, 2: segments dealt to the lanes by the kind of hit)")
     ap.add_argument("--no-leaves-compare", action="store_true",
                     help="skip the second timed leg (N = 1 only) that renders the same steps with the OTHER leaf mode for `leaves_compare`")
+    ap.add_argument("--dispatch-per-step", action="store_true",
+                    help="one ptmi_dispatch per step instead of one for all K steps (the library then cannot interleave the batches)")
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1 from ONE process: ptmi_multi_* (one host thread, one stream per device, the library's own RCCL gather) "
                          "instead of one rank per GPU under torch.distributed")
@@ -438,10 +440,17 @@ def main():
 
     frame_index = 0
 
-    def step():
+    def step(n=1):
+        """n steps = n batches of fps frames. They go to the library as ONE dispatch: it runs consecutive batches interleaved (batch
+        k + 1 enters when batch k has done half its bounces; csrc/ptmi_api.hip), which separate dispatches would not let it do."""
         nonlocal frame_index
-        ctx.dispatch(layout.make_camera(W, H, frame_index=frame_index, **cam_kw), fps)
-        frame_index += fps
+        if args.dispatch_per_step:
+            for _ in range(n):
+                ctx.dispatch(layout.make_camera(W, H, frame_index=frame_index, **cam_kw), fps)
+                frame_index += fps
+        elif n:
+            ctx.dispatch(layout.make_camera(W, H, frame_index=frame_index, **cam_kw), fps * n)
+            frame_index += fps * n
 
     # row indices, the packed send buffer and the root's receive buffers exist before any timed step (shard.StripGather)
     strip_gather = shard.StripGather(frame, world, rank, strip) if world > 1 and not args.rehearse else None
@@ -462,14 +471,12 @@ def main():
         torch.cuda.synchronize()
 
     t_leg = time.perf_counter()
-    for _ in range(args.warmup):
-        step()
+    step(args.warmup)
     gather()                                  # also sets up the RCCL channels outside the timed region
     fence()
     ctx.reset_stats()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
+    step(steps)
     gather()
     fence()
     dt = time.perf_counter() - t0
@@ -484,13 +491,11 @@ def main():
         ctx.set_options(leaves=other)
         ctx.upload_scene(scene)
         frame_index = 0
-        for _ in range(args.warmup):
-            step()
+        step(args.warmup)
         fence()
         ctx.reset_stats()
         t1 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        step(steps)
         fence()
         dt2 = time.perf_counter() - t1
         st2 = ctx.stats()
@@ -579,6 +584,7 @@ def main():
                 **({"perf_mode": args.perf_mode} if args.perf_mode else {}),
                 "leaves": int(st.leaves_used), "leaf_tris": int(st.leaf_tris_used),
                 "extend_variant": int(st.extend_variant), "shadow_variant": int(st.shadow_variant), "shade_sort": int(st.shade_sort_used),
+                "batches_interleaved": bool(st.interleaved), "dispatches": int(st.dispatches),
             },
             "verify_failed_rank0": int(st.verify_failed),
             **({"leaves_compare": leaves_compare} if leaves_compare else {}),

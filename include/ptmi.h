@@ -53,7 +53,9 @@ typedef struct ptmi_options {
     uint32_t do_mis;            /* 0/1; default 1 */
     uint32_t tile_y0, tile_y1;  /* rows [y0,y1) this context renders; y1 = 0 -> height. Other rows are untouched */
     uint32_t frames_per_batch;  /* frames traced together as one wavefront batch; 0 -> auto (up to 64 frames / ~128 Mi paths, ~23 GB of
-                                   path state at 1920x1080; a dispatch of fewer frames is one smaller batch) */
+                                   path state at 1920x1080; a dispatch of fewer frames is one smaller batch). A dispatch of more frames
+                                   is several batches, run interleaved — batch k + 1 enters when batch k has done half its bounces, the
+                                   two share every launch — with the state of two batches resident (~45 GB) */
     uint32_t traversal;         /* PTMI_TRAVERSAL_*; AUTO picks LDS when the scene fits */
     uint32_t cull;              /* 1 (default): ordered traversal with conservative distance cull;
                                    0: every box-overlapping leaf is tested, as pt.wgsl:248-291 does */
@@ -136,7 +138,8 @@ typedef struct ptmi_stats {
      * uploaded tree (both kernels together), since the last reset */
     uint64_t verify_failed;
     uint32_t shade_sort_used;   /* 1 / 2: ptmi_options.shade_sort as the last dispatch ran */
-    uint32_t reserved_stats;
+    uint32_t interleaved;       /* 1: the last dispatch had several batches and ran them interleaved (batch k + 1 starts when batch k has
+                                   done half its bounces; both share the launches — csrc/ptmi_api.hip ptmi_dispatch) */
 } ptmi_stats;
 
 /* ---- lifetime ----------------------------------------------------------- */

@@ -697,27 +697,39 @@ bool pt_quantize_nodes(const std::vector<float4> &wnodes, std::vector<uint4> &qn
         for (size_t i = 0; i < n_nodes; i++) if (renum[i] == 0xFFFFFFFFu) renum[i] = next++;
     }
     qnodes.resize(n_nodes * 2);
-    double growth = 0.0; size_t grown = 0;
-    for (size_t i = 0; i < n_nodes; i++) {
-        const float4 *w = &wnodes[i * 4];
-        const float lo[2][3] = {{w[0].x, w[0].y, w[0].z}, {w[1].z, w[1].w, w[2].x}};
-        const float hi[2][3] = {{w[0].w, w[1].x, w[1].y}, {w[2].y, w[2].z, w[2].w}};
-        uint32_t refs[2]; std::memcpy(&refs[0], &w[3].x, 4); std::memcpy(&refs[1], &w[3].y, 4);
-        for (int c = 0; c < 2; c++) {
-            uint32_t ql[3], qh[3];
-            float dl[3], dh[3];
-            for (int k = 0; k < 3; k++) {
-                ql[k] = plane_lo(k, lo[c][k]); qh[k] = plane_hi(k, hi[c][k]);
-                dl[k] = std::fmaf(scale[k], (float)ql[k], origin[k]); dh[k] = std::fmaf(scale[k], (float)qh[k], origin[k]);
+    auto fill = [&](size_t i0, size_t i1, double &growth, size_t &grown) {
+        for (size_t i = i0; i < i1; i++) {
+            const float4 *w = &wnodes[i * 4];
+            const float lo[2][3] = {{w[0].x, w[0].y, w[0].z}, {w[1].z, w[1].w, w[2].x}};
+            const float hi[2][3] = {{w[0].w, w[1].x, w[1].y}, {w[2].y, w[2].z, w[2].w}};
+            uint32_t refs[2]; std::memcpy(&refs[0], &w[3].x, 4); std::memcpy(&refs[1], &w[3].y, 4);
+            for (int c = 0; c < 2; c++) {
+                uint32_t ql[3], qh[3];
+                float dl[3], dh[3];
+                for (int k = 0; k < 3; k++) {
+                    ql[k] = plane_lo(k, lo[c][k]); qh[k] = plane_hi(k, hi[c][k]);
+                    dl[k] = std::fmaf(scale[k], (float)ql[k], origin[k]); dh[k] = std::fmaf(scale[k], (float)qh[k], origin[k]);
+                }
+                const uint32_t ref = (refs[c] & PT_REF_LEAF) ? refs[c] : renum[refs[c]];
+                qnodes[(size_t)renum[i] * 2 + c] = make_uint4(ql[0] | (ql[1] << 16), ql[2] | (qh[0] << 16), qh[1] | (qh[2] << 16), ref);
+                const double ax = (double)hi[c][0] - lo[c][0], ay = (double)hi[c][1] - lo[c][1], az = (double)hi[c][2] - lo[c][2];
+                const double a0 = 2.0 * (ax * ay + ay * az + az * ax);
+                const double bx = (double)dh[0] - dl[0], by = (double)dh[1] - dl[1], bz = (double)dh[2] - dl[2];
+                if (a0 > 0.0) { growth += std::min(2.0 * (bx * by + by * bz + bz * bx) / a0 - 1.0, 1e6); grown++; }
             }
-            const uint32_t ref = (refs[c] & PT_REF_LEAF) ? refs[c] : renum[refs[c]];
-            qnodes[(size_t)renum[i] * 2 + c] = make_uint4(ql[0] | (ql[1] << 16), ql[2] | (qh[0] << 16), qh[1] | (qh[2] << 16), ref);
-            const double ax = (double)hi[c][0] - lo[c][0], ay = (double)hi[c][1] - lo[c][1], az = (double)hi[c][2] - lo[c][2];
-            const double a0 = 2.0 * (ax * ay + ay * az + az * ax);
-            const double bx = (double)dh[0] - dl[0], by = (double)dh[1] - dl[1], bz = (double)dh[2] - dl[2];
-            if (a0 > 0.0) { growth += std::min(2.0 * (bx * by + by * bz + bz * bx) / a0 - 1.0, 1e6); grown++; }
         }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t n_thr = n_nodes < 65536 ? 1 : std::min<size_t>(16, hw ? hw : 1);
+    std::vector<double> g(n_thr, 0.0); std::vector<size_t> gn(n_thr, 0);
+    {
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < n_thr; t++) pool.emplace_back([&, t] { fill(n_nodes * t / n_thr, n_nodes * (t + 1) / n_thr, g[t], gn[t]); });
+        fill(0, n_nodes / n_thr, g[0], gn[0]);
+        for (auto &th : pool) th.join();
     }
+    double growth = 0.0; size_t grown = 0;
+    for (size_t t = 0; t < n_thr; t++) { growth += g[t]; grown += gn[t]; }
     if (grown && growth / (double)grown > 0.25) { qnodes.clear(); return false; }       // a 16-bit grid is too coarse for this scene's boxes
     return true;
 }

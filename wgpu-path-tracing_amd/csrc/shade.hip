@@ -309,6 +309,7 @@ __global__ __launch_bounds__(SBLOCK) PT_SHADE_ATTR void k_shade(DevScene sc, Dev
     __shared__ uint16_t s_perm[SBLOCK];
     __shared__ uint8_t s_flags[SBLOCK];
     const uint32_t count = *count_ptr;
+    const uint32_t boundary = *sp.boundary;   // slots below it: the older batch (bounce_a); from it on: the newer one (bounce_b)
     uint32_t n_skipped = 0, n_emitted = 0;  // lane 0 of each wave: one atomic per wave at the end
     for (uint32_t base = blockIdx.x * SBLOCK; base < count; base += gridDim.x * SBLOCK) {
         uint32_t i = base + threadIdx.x;
@@ -337,7 +338,8 @@ __global__ __launch_bounds__(SBLOCK) PT_SHADE_ATTR void k_shade(DevScene sc, Dev
         }
         bool alive = false, shadow = false, skipped = false, emitted = false;
         if (i < count) {
-            const uint32_t q = queue ? queue[i] : i;                         // where this ray's state is
+            const uint32_t q = queue ? queue[i] : i + sp.id_base;            // where this ray's state is
+            const uint32_t bounce = i < boundary ? sp.bounce_a : sp.bounce_b;
             const float2 h2 = ld_stream(&hits[i]);
             if (!(h2.x < 0.0f)) {                                            // pt.wgsl:646: miss adds zero
                 const float4 o4 = ld_stream(&P.O[q]), d4 = ld_stream(&P.D[q]);
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(SBLOCK) PT_SHADE_ATTR void k_shade(DevScene sc, Dev
                 uint32_t rng = __float_as_uint(o4.w);
                 const v3 ro = xyz(o4), rd = xyz(d4);
                 v3 thr = mk3(1.0f, 1.0f, 1.0f);                                      // pt.wgsl:639; raygen stores no throughput
-                if (sp.bounce != 0u) { const float2 c2 = ld_stream(&P.C[q]); thr = mk3(d4.w, c2.x, c2.y); }
+                if (bounce != 0u) { const float2 c2 = ld_stream(&P.C[q]); thr = mk3(d4.w, c2.x, c2.y); }
                 const HitInfo hit = make_hitinfo(sc, ro, rd, h2.x, __float_as_uint(h2.y));
                 if (hit.emission.x > 0.0f || hit.emission.y > 0.0f || hit.emission.z > 0.0f) {   // pt.wgsl:652-658
                     float att = rcp1(1.0f + hit.t * hit.t);
@@ -393,19 +395,20 @@ __global__ __launch_bounds__(SBLOCK) PT_SHADE_ATTR void k_shade(DevScene sc, Dev
                         v3 nd = normalize3(dir);
                         thr = mul3(thr, vdiv3(mk3(ev.x, ev.y, ev.z), max1(ev.w, PT_EPS)));   // pt.wgsl:696
                         alive = true;
-                        if (sp.bounce > 2u) {                                 // pt.wgsl:699-705
+                        if (bounce > 2u) {                                    // pt.wgsl:699-705
                             float pr = max1(max1(thr.x, thr.y), thr.z);
                             if (rng_f(rng) > pr) alive = false;
                             else thr = vdiv3(thr, pr);
                         }
-                        if (alive && sp.bounce + 1u < sp.max_bounces) {
+                        alive = alive & (bounce + 1u < sp.max_bounces);       // pt.wgsl:642: the loop ends; compaction drops the path
+                        if (alive) {
                             st_stream(&P.O[q], make_float4(no.x, no.y, no.z, __uint_as_float(rng)));
                             st_stream(&P.D[q], make_float4(nd.x, nd.y, nd.z, thr.x));
                             st_stream(&P.C[q], make_float2(thr.y, thr.z));
                         }
                     }
                 }
-            } else if (sp.bounce != 0u) {
+            } else if (bounce != 0u) {
                 // pt.wgsl:646-648: a miss adds `throughput * vec3f(0.0)` — nothing while the throughput is finite (x + +-0 = x, and
                 // the radiance is never -0), NaN in every component whose throughput is infinite or NaN (degenerate materials
                 // only; the camera ray's throughput is 1). Such a path leaves a record like an emissive hit's.

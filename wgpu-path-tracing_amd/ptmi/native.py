@@ -62,7 +62,7 @@ class Stats(ctypes.Structure):
                 ("upload_ms", ctypes.c_double), ("upload_tree_ms", ctypes.c_double), ("upload_copy_ms", ctypes.c_double),
                 ("leaves_used", ctypes.c_uint32), ("leaf_tris_used", ctypes.c_uint32),
                 ("extend_variant", ctypes.c_uint32), ("shadow_variant", ctypes.c_uint32), ("verify_failed", ctypes.c_uint64),
-                ("shade_sort_used", ctypes.c_uint32), ("reserved_stats", ctypes.c_uint32)]
+                ("shade_sort_used", ctypes.c_uint32), ("interleaved", ctypes.c_uint32)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("segments_by_bounce",)}
