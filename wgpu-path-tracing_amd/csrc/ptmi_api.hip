@@ -208,8 +208,9 @@ int ensure_capacity(ptmi_ctx *c, Lane &ln, size_t n, size_t n_paths = 0) {
         return fail(c, PTMI_E_HIP, "hipMalloc of %zu bytes for a batch of %zu paths failed: %s", (size_t)(bytes), cap, hipGetErrorString(e_)); } } while (0)
     ALLOC(ln.paths.O, pcap * 16); ALLOC(ln.paths.D, pcap * 16);
     ALLOC(ln.paths.C, pcap * 8); ALLOC(ln.paths.L, pcap * 16);      // room for either stride
-    {   // the radiance starts at zero and every accumulate leaves it so (pipeline.hip k_accumulate)
-        hipError_t e_ = hipMemset(ln.paths.L, 0, pcap * 16);
+    {   // the radiance starts at zero and every accumulate leaves it so (pipeline.hip k_accumulate). On the context's stream: the
+        // streams are non-blocking, a memset on the default stream would not be ordered before their kernels
+        hipError_t e_ = hipMemsetAsync(ln.paths.L, 0, pcap * 16, c->stream);
         if (e_ != hipSuccess) { free_batch(ln); return fail(c, PTMI_E_HIP, "hipMemset failed: %s", hipGetErrorString(e_)); }
     }
     ALLOC(ln.hits, cap * 8);
