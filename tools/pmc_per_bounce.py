@@ -20,7 +20,7 @@ def main(paths, bounces):
             if not m:
                 continue
             k = m.group(1)
-            if k.startswith("k_trace"):
+            if k.startswith(("k_trace", "k_own")):
                 k = "shadow" if "ShadowIO" in name else "extend"
             elif k == "k_shade":
                 k = "shade"

@@ -41,7 +41,7 @@ for c in (1, 3, 2, 4):
     if os.path.exists(p):
         for row in csv.DictReader(open(p)):
             nm = row["Name"]
-            key = ("shadow" if "ShadowIO" in nm else "extend") if "k_trace" in nm else \
+            key = ("shadow" if "ShadowIO" in nm else "extend") if ("k_trace" in nm or "k_own" in nm) else \
                   next((k for k in ("k_shade", "k_raygen", "k_accumulate", "k_scatter2", "k_scatter", "k_tile_sums") if k + "(" in nm), None)
             if key:
                 stats[key] = (int(row["Calls"]), float(row["TotalDurationNs"]) / 1e6, float(row["AverageNs"]) / 1e3)

@@ -13,7 +13,7 @@ def main(path, n_last=70):
         name = r["Kernel_Name"]
         m = re.search(r"(k_\w+)", name)
         k = m.group(1) if m else name[:24]
-        if k.startswith("k_trace"):
+        if k.startswith(("k_trace", "k_own")):
             k = ("shadow" if "ShadowIO" in name else "extend") + ("_lds" if "lds" in k else "_glb")
         b = seen.get(k, 0); seen[k] = b + 1
         s, e = (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3
