@@ -331,11 +331,8 @@ def main():
     ap.add_argument("--leaves", type=int, default=None,
                     help="library option leaves, read at upload (1: the uploaded BVH's leaves; 2: the library's own leaves; default: the library's)")
     ap.add_argument("--leaf-tris", type=int, default=None, help="library option leaf_tris (most triangles per own leaf)")
-    ap.add_argument("--shade-sort", type=int, default=None, help="library option shade_sort (1: off, 2: segments dealt to the lanes by the kind of hit)")
     ap.add_argument("--no-leaves-compare", action="store_true",
                     help="skip the second timed leg (N = 1 only) that renders the same steps with the OTHER leaf mode for `leaves_compare`")
-    ap.add_argument("--dispatch-per-step", action="store_true",
-                    help="one ptmi_dispatch per step instead of one for all K steps (the library then cannot interleave the batches)")
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1 from ONE process: ptmi_multi_* (one host thread, one stream per device, the library's own RCCL gather) "
                          "instead of one rank per GPU under torch.distributed")
@@ -433,24 +430,15 @@ def main():
         extra["perf_mode"] = args.perf_mode
     if args.overlap is not None:
         extra["overlap"] = args.overlap
-    if args.shade_sort is not None:
-        extra["shade_sort"] = args.shade_sort
     ctx.set_options(max_bounces=cfg["bounces"], do_mis=mis, frames_per_batch=args.frames_per_batch, traversal=trav, cull=1,
                     timing=args.timing, **extra, **shard.strip_options(world, rank, strip))
 
     frame_index = 0
 
-    def step(n=1):
-        """n steps = n batches of fps frames. They go to the library as ONE dispatch: it runs consecutive batches interleaved (batch
-        k + 1 enters when batch k has done half its bounces; csrc/ptmi_api.hip), which separate dispatches would not let it do."""
+    def step():
         nonlocal frame_index
-        if args.dispatch_per_step:
-            for _ in range(n):
-                ctx.dispatch(layout.make_camera(W, H, frame_index=frame_index, **cam_kw), fps)
-                frame_index += fps
-        elif n:
-            ctx.dispatch(layout.make_camera(W, H, frame_index=frame_index, **cam_kw), fps * n)
-            frame_index += fps * n
+        ctx.dispatch(layout.make_camera(W, H, frame_index=frame_index, **cam_kw), fps)
+        frame_index += fps
 
     # row indices, the packed send buffer and the root's receive buffers exist before any timed step (shard.StripGather)
     strip_gather = shard.StripGather(frame, world, rank, strip) if world > 1 and not args.rehearse else None
@@ -471,12 +459,14 @@ def main():
         torch.cuda.synchronize()
 
     t_leg = time.perf_counter()
-    step(args.warmup)
+    for _ in range(args.warmup):
+        step()
     gather()                                  # also sets up the RCCL channels outside the timed region
     fence()
     ctx.reset_stats()
     t0 = time.perf_counter()
-    step(steps)
+    for _ in range(steps):
+        step()
     gather()
     fence()
     dt = time.perf_counter() - t0
@@ -491,11 +481,13 @@ def main():
         ctx.set_options(leaves=other)
         ctx.upload_scene(scene)
         frame_index = 0
-        step(args.warmup)
+        for _ in range(args.warmup):
+            step()
         fence()
         ctx.reset_stats()
         t1 = time.perf_counter()
-        step(steps)
+        for _ in range(steps):
+            step()
         fence()
         dt2 = time.perf_counter() - t1
         st2 = ctx.stats()
@@ -532,8 +524,7 @@ def main():
         # same view), so they apply whatever --steps / --warmup are; any flag that changes the dispatch itself rules them out
         is_profiled = (not overridden and world == 1 and args.traversal == "auto"
                        and not args.perf_mode and args.overlap is None and not args.keep_reference_tree
-                       and args.frames_per_batch == 0 and args.tree_builder is None and args.leaves is None and args.leaf_tris is None
-                       and args.shade_sort is None)
+                       and args.frames_per_batch == 0 and args.tree_builder is None and args.leaves is None and args.leaf_tris is None)
         traffic, traffic_src = pmc_traffic(args.config, is_profiled)
 
         def kernel_entry(label, name, ms, launches, units, bytes_per_unit):
@@ -583,8 +574,7 @@ def main():
                 "triangles": int(len(scene.tris)), "bvh_nodes": int(len(scene.nodes)), "parallelism": par,
                 **({"perf_mode": args.perf_mode} if args.perf_mode else {}),
                 "leaves": int(st.leaves_used), "leaf_tris": int(st.leaf_tris_used),
-                "extend_variant": int(st.extend_variant), "shadow_variant": int(st.shadow_variant), "shade_sort": int(st.shade_sort_used),
-                "batches_interleaved": bool(st.interleaved), "dispatches": int(st.dispatches),
+                "extend_variant": int(st.extend_variant), "shadow_variant": int(st.shadow_variant),
             },
             "verify_failed_rank0": int(st.verify_failed),
             **({"leaves_compare": leaves_compare} if leaves_compare else {}),

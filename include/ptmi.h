@@ -53,9 +53,7 @@ typedef struct ptmi_options {
     uint32_t do_mis;            /* 0/1; default 1 */
     uint32_t tile_y0, tile_y1;  /* rows [y0,y1) this context renders; y1 = 0 -> height. Other rows are untouched */
     uint32_t frames_per_batch;  /* frames traced together as one wavefront batch; 0 -> auto (up to 64 frames / ~128 Mi paths, ~23 GB of
-                                   path state at 1920x1080; a dispatch of fewer frames is one smaller batch). A dispatch of more frames
-                                   is several batches, run interleaved — batch k + 1 enters when batch k has done half its bounces, the
-                                   two share every launch — with the state of two batches resident (~45 GB) */
+                                   path state at 1920x1080; a dispatch of fewer frames is one smaller batch) */
     uint32_t traversal;         /* PTMI_TRAVERSAL_*; AUTO picks LDS when the scene fits */
     uint32_t cull;              /* 1 (default): ordered traversal with conservative distance cull;
                                    0: every box-overlapping leaf is tested, as pt.wgsl:248-291 does */
@@ -99,10 +97,7 @@ typedef struct ptmi_options {
                                        traced again over the uploaded tree, so results equal mode 1's;
                                    0 = library default (2) */
     uint32_t leaf_tris;         /* leaves = 2: most triangles per own leaf, 1 .. 32; 0 = library default (measured: profiles/README.md) */
-    uint32_t shade_sort;        /* 1 = `shade` takes the segments of a queue in slot order; 2 = from bounce 1 on each workgroup deals the 256
-                                   segments of a round to its lanes by the kind of hit (miss / emissive / transmissive / metallic / diffuse
-                                   material), so that a wave runs one branch of pt.wgsl:646-705 instead of all of them. Every segment is
-                                   computed by the same operations and written to its own slot: same results. 0 = library default */
+    uint32_t reserved[1];       /* must be 0 */
 } ptmi_options;
 
 typedef struct ptmi_stats {
@@ -137,9 +132,7 @@ typedef struct ptmi_stats {
     /* leaves = 2: closest hits / occluders whose reference leaf's box did not pass and rays that were therefore traced again over the
      * uploaded tree (both kernels together), since the last reset */
     uint64_t verify_failed;
-    uint32_t shade_sort_used;   /* 1 / 2: ptmi_options.shade_sort as the last dispatch ran */
-    uint32_t interleaved;       /* 1: the last dispatch had several batches and ran them interleaved (batch k + 1 starts when batch k has
-                                   done half its bounces; both share the launches — csrc/ptmi_api.hip ptmi_dispatch) */
+    uint32_t reserved_stats[2];
 } ptmi_stats;
 
 /* ---- lifetime ----------------------------------------------------------- */

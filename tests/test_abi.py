@@ -46,16 +46,16 @@ def test_abi_version_and_struct_sizes(lib):
     assert lib.ptmi_abi_version() == native.ABI_VERSION == 4
     assert ctypes.sizeof(native.Options) == 23 * 4      # ABI 4: the size of ABI 3 (five of its options are reserved words now; leaves, leaf_tris are new)
     # ptmi_stats: 5 + 64 u64, 2 f64 + u64 + 2 f64, 4 u32; ABI 2 adds 3 u64 + 6 f64
-    assert ctypes.sizeof(native.Stats) == (5 + 64) * 8 + 5 * 8 + 16 + 9 * 8 + 16 + 8 + 8      # ABI 4: leaves_used, leaf_tris_used, two variants, verify_failed, shade_sort_used + a reserved word
+    assert ctypes.sizeof(native.Stats) == (5 + 64) * 8 + 5 * 8 + 16 + 9 * 8 + 16 + 8 + 8      # ABI 4: leaves_used, leaf_tris_used, two variants, verify_failed, two reserved words
 
 
 def test_ctypes_structs_match_the_header(tmp_path):
     """sizeof / offsetof of every struct the binding mirrors, as a C compiler lays out include/ptmi.h."""
     from ptmi import native
     src = tmp_path / "sizes.c"
-    fields = {"ptmi_options": ["max_bounces", "timing", "tile_strip", "perf_mode", "reserved_a", "overlap", "reserved_b", "tree_builder", "leaves", "leaf_tris", "shade_sort"],
+    fields = {"ptmi_options": ["max_bounces", "timing", "tile_strip", "perf_mode", "reserved_a", "overlap", "reserved_b", "tree_builder", "leaves", "leaf_tris", "reserved"],
               "ptmi_stats": ["paths", "segments_by_bounce", "gpu_ms", "extend_launches", "bvh_depth", "shadow_traced",
-                             "raygen_ms", "upload_copy_ms", "leaves_used", "leaf_tris_used", "extend_variant", "shadow_variant", "verify_failed", "shade_sort_used"]}
+                             "raygen_ms", "upload_copy_ms", "leaves_used", "leaf_tris_used", "extend_variant", "shadow_variant", "verify_failed"]}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "ptmi.h"', 'int main(void) {']
     for st, fs in fields.items():
         lines.append(f'printf("{st} %zu\\n", sizeof({st}));')

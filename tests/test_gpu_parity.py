@@ -421,76 +421,3 @@ def test_interleaved_strips_cover_the_frame(gpu_ctx, oracle, scene_factory, part
     with pytest.raises(Exception):
         gpu_ctx.set_options(tile_parts=2, tile_part=2)
     gpu_ctx.set_options(tile_y0=0, tile_y1=0, tile_parts=0, tile_part=0, tile_strip=0)
-
-
-@pytest.mark.parametrize("name", ["cornell", "cornell_glass", "feature_box", "cornell_spheres"])
-def test_shade_sort_is_invisible(gpu_ctx, oracle, scene_factory, name):
-    """shade_sort = 2: from bounce 1 on every workgroup of `shade` deals the 256 segments of a round to its lanes by the kind of hit
-    (miss / emissive / transmissive / metallic / diffuse material) — other lanes, same segments, results written to the segment's own
-    slot, ballot words rebuilt in slot order. The image and the counters must not move by a bit: 200x130 pixels x 5 frames (queues
-    that end inside a 256-slot round), several batches per dispatch, 1 / 2 / 8 bounces, both streams modes (pt.wgsl:646-705)."""
-    sc = scene_factory(name)
-    W, H, frames = 200, 130, 5
-    cam = layout.make_camera(W, H, aperture=0.02, focus_distance=2.8)
-    gpu_ctx.upload_scene(sc)
-    for bounces in (8, 2, 1):
-        ref, ost = oracle.render(sc, cam, frames, max_bounces=bounces, do_mis=1)
-        for sort, fpb, overlap in ((2, 0, 1), (2, 2, 1), (2, 0, 0), (1, 0, 1)):
-            gpu_ctx.resize(W, H)
-            gpu_ctx.set_options(max_bounces=bounces, do_mis=1, tile_y0=0, tile_y1=0, tile_parts=0, frames_per_batch=fpb, cull=1, traversal=0,
-                                shade_sort=sort, overlap=overlap)
-            gpu_ctx.reset_stats()
-            gpu_ctx.dispatch(cam, frames)
-            got = gpu_ctx.read_output()
-            st = gpu_ctx.stats()
-            assert st.shade_sort_used == sort
-            assert (st.segments, st.shadow_rays, st.paths) == (ost.segments, ost.shadow_rays, ost.paths)
-            assert_same_floats(got, ref, f"radiance ({name}, shade_sort {sort}, frames_per_batch {fpb}, overlap {overlap}, {bounces} bounces)")
-    gpu_ctx.set_options(shade_sort=0, frames_per_batch=0, overlap=2, max_bounces=8)
-
-
-@pytest.mark.parametrize("name,trav", [("cornell", 0), ("feature_box", 0), ("cornell_spheres", 1)])
-def test_interleaved_batches_are_invisible(gpu_ctx, oracle, scene_factory, name, trav, monkeypatch):
-    """A dispatch of several batches runs them INTERLEAVED (csrc/ptmi_api.hip ptmi_dispatch): batch k + 1 enters when batch k has done half
-    its bounces and both share every launch — the older batch's survivors in front of the newer batch's in one queue, `shade` telling
-    their bounces apart by the slot. Every path still sees its own operations in its own order (pt.wgsl:638-709) and `accumulate` its
-    frames in frame order (:753-761): 9 frames as batches of 1 / 2 / 4 / 9 frames, 1 ... 8 bounces (odd counts: the older batch ends
-    before the next one enters), MIS on and off, one stream and two, and the same dispatches with interleaving switched off — all
-    must leave the oracle's bits and counters."""
-    sc = scene_factory(name)
-    W, H, frames = 120, 70, 9
-    cam = layout.make_camera(W, H, aperture=0.02, focus_distance=2.8)
-    gpu_ctx.upload_scene(sc)
-    for bounces, mis in ((8, 1), (7, 1), (5, 0), (3, 1), (2, 1), (1, 1)):
-        ref, ost = oracle.render(sc, cam, frames, max_bounces=bounces, do_mis=mis)
-        for fpb, overlap, inter in ((2, 1, "1"), (1, 1, "1"), (4, 0, "1"), (9, 1, "1"), (2, 1, "0")):
-            monkeypatch.setenv("PTMI_INTERLEAVE", inter)
-            gpu_ctx.resize(W, H)
-            gpu_ctx.set_options(max_bounces=bounces, do_mis=mis, tile_y0=0, tile_y1=0, tile_parts=0, frames_per_batch=fpb, cull=1,
-                                traversal=trav, overlap=overlap, timing=3)
-            gpu_ctx.reset_stats()
-            gpu_ctx.dispatch(cam, frames)
-            got = gpu_ctx.read_output()
-            st = gpu_ctx.stats()
-            assert st.interleaved == (1 if inter == "1" and fpb < frames and bounces >= 2 else 0)
-            assert (st.segments, st.shadow_rays, st.paths) == (ost.segments, ost.shadow_rays, ost.paths)
-            assert [int(v) for v in st.segments_by_bounce[:bounces]] == [int(v) for v in oracle_segments_by_bounce(oracle, sc, cam, frames, bounces, mis)]
-            assert_same_floats(got, ref, f"radiance ({name}, {bounces} bounces, MIS {mis}, frames_per_batch {fpb}, overlap {overlap}, interleave {inter})")
-    # two dispatches back to back on the same buffers (frames 0..8, then 9..13 on top)
-    monkeypatch.setenv("PTMI_INTERLEAVE", "1")
-    gpu_ctx.resize(W, H)
-    gpu_ctx.set_options(max_bounces=8, do_mis=1, frames_per_batch=2, overlap=2, timing=0, traversal=0)
-    gpu_ctx.dispatch(cam, 9)
-    gpu_ctx.dispatch(layout.make_camera(W, H, aperture=0.02, focus_distance=2.8, frame_index=9), 5)
-    ref, _ = oracle.render(sc, cam, 14, max_bounces=8, do_mis=1)
-    assert_same_floats(gpu_ctx.read_output(), ref, "14 frames in two interleaved dispatches")
-    gpu_ctx.set_options(frames_per_batch=0)
-
-
-def oracle_segments_by_bounce(oracle, sc, cam, frames, bounces, mis):
-    """segments per bounce = what a render limited to b + 1 bounces traces more than one limited to b"""
-    tot = [0]
-    for b in range(1, bounces + 1):
-        _, st = oracle.render(sc, cam, frames, max_bounces=b, do_mis=mis)
-        tot.append(st.segments)
-    return [tot[i + 1] - tot[i] for i in range(bounces)]

@@ -39,32 +39,25 @@ PT_DEV void camera_ray(const ptmi_camera &cam, uint32_t x, uint32_t y, uint32_t 
 }
 
 // The throughput of pt.wgsl:639 is not stored: `shade` knows it is (1, 1, 1) at bounce 0 and writes D.w / C from then on.
-// The radiance of pt.wgsl:640 is zero already: k_accumulate leaves it so (ZERO_L: the per-stage entry point, which has no accumulate).
-template <bool ZERO_L>
 PT_DEV void init_path(DevPaths P, uint32_t p, v3 o, v3 d, uint32_t rng) {
     P.O[p] = make_float4(o.x, o.y, o.z, __uint_as_float(rng));
     P.D[p] = make_float4(d.x, d.y, d.z, 0.0f);
-    if (ZERO_L) P.stL(p, 0.0f, 0.0f, 0.0f);
+    P.stL(p, 0.0f, 0.0f, 0.0f);                        // pt.wgsl:640
 }
 
-// path id = id_base + frame_in_batch * band_pixels + local_row * width + x (local rows: DevBand::row_of). A batch that starts alone has
-// the identity as its bounce-0 queue, which is not materialised: extend / shade / compact take a null queue as "slot i holds path
-// id_base + i". A batch that starts behind the survivors of the one before it (interleaved batches, pt_device.h) appends its ids to theirs.
+// path id = frame_in_batch * band_pixels + local_row * width + x (local rows: DevBand::row_of). The bounce-0 queue is the identity and is
+// not materialised: extend / shade / compact take a null queue as "slot i holds path i".
 __global__ __launch_bounds__(BLOCK) void k_raygen(ptmi_camera cam, DevBand band, uint32_t frame0, uint32_t n_frames,
-                                                  DevPaths P, uint32_t id_base, const uint32_t *__restrict__ count_in,
-                                                  uint32_t *__restrict__ count_out, uint32_t *__restrict__ boundary_out,
-                                                  uint32_t *__restrict__ queue) {
+                                                  DevPaths P, uint32_t *__restrict__ count_out) {
     const uint32_t npix = band.rows * band.width;
     const uint32_t total = npix * n_frames;
-    const uint32_t old = count_in ? *count_in : 0u;              // (count_in and count_out are different words: no thread reads what another writes)
-    if (blockIdx.x == 0 && threadIdx.x == 0) { *count_out = old + total; *boundary_out = old; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = total;
     for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < total; p += gridDim.x * BLOCK) {
         uint32_t k = p / npix, pix = p - k * npix;
         uint32_t y = band.row_of(pix / band.width), x = pix % band.width;
         v3 o, d; uint32_t rng;
         camera_ray(cam, x, y, frame0 + k, o, d, rng);
-        init_path<false>(P, id_base + p, o, d, rng);
-        if (queue) queue[old + p] = id_base + p;
+        init_path(P, p, o, d, rng);
     }
 }
 
@@ -74,7 +67,7 @@ __global__ __launch_bounds__(BLOCK) void k_raygen_list(ptmi_camera cam, uint32_t
     if (p >= n) return;
     v3 o, d; uint32_t rng;
     camera_ray(cam, xs[p], ys[p], frames[p], o, d, rng);
-    init_path<true>(P, p, o, d, rng);
+    init_path(P, p, o, d, rng);
 }
 
 // ---- ordered compaction ------------------------------------------------------
@@ -100,16 +93,12 @@ __global__ __launch_bounds__(TILE_WORDS) void k_tile_sums(const uint32_t *__rest
                                                           const uint64_t *__restrict__ shadow,
                                                           uint32_t *__restrict__ tile_sums,
                                                           uint32_t *__restrict__ shadow_tile_sums,
-                                                          unsigned long long *__restrict__ stats, uint32_t bounce_a, uint32_t bounce_b,
-                                                          const uint32_t *__restrict__ boundary_ptr) {
+                                                          unsigned long long *__restrict__ stats, uint32_t bounce) {
     __shared__ uint32_t wsum[TILE_WAVES], wssum[TILE_WAVES];
     const uint32_t count = *count_ptr;
     const uint32_t nwords = (count + 63u) >> 6;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {          // the segments of this launch, by the bounce their batch is at
-        const uint32_t na = *boundary_ptr < count ? *boundary_ptr : count;
-        atomicAdd(&stats[0], (unsigned long long)count);
-        if (na) atomicAdd(&stats[8 + bounce_a], (unsigned long long)na);
-        if (count - na) atomicAdd(&stats[8 + bounce_b], (unsigned long long)(count - na));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {          // atomics: two batches may be in flight on two lanes
+        atomicAdd(&stats[0], (unsigned long long)count); atomicAdd(&stats[8 + bounce], (unsigned long long)count);
     }
     if (blockIdx.x * TILE_WORDS >= nwords) return;
     const uint32_t w = blockIdx.x * TILE_WORDS + threadIdx.x;
@@ -127,19 +116,16 @@ __global__ __launch_bounds__(TILE_WORDS) void k_tile_sums(const uint32_t *__rest
     }
 }
 
-// boundary_ptr / next_boundary (survivor compaction only; NULL for the shadow index list): *next_boundary = the survivors among the slots
-// below *boundary_ptr — where the newer batch's part of the next queue begins
 PT_DEV void scatter_tile(uint32_t tile, const uint32_t *__restrict__ count_ptr, const uint32_t *__restrict__ queue,
                          const uint64_t *__restrict__ alive, const uint32_t *__restrict__ tile_sums,
-                         uint32_t *__restrict__ next_queue, uint32_t *__restrict__ next_count, uint32_t id_base = 0,
-                         const uint32_t *__restrict__ boundary_ptr = nullptr, uint32_t *__restrict__ next_boundary = nullptr) {
+                         uint32_t *__restrict__ next_queue, uint32_t *__restrict__ next_count) {
     __shared__ uint32_t wtot[TILE_WAVES];
     __shared__ uint32_t tile_base;
     const uint32_t count = *count_ptr;
     const uint32_t nwords = (count + 63u) >> 6;
     const uint32_t ntiles = (nwords + TILE_WORDS - 1) / TILE_WORDS;
     if (tile >= ntiles) {
-        if (ntiles == 0 && tile == 0 && threadIdx.x == 0) { *next_count = 0; if (next_boundary) *next_boundary = 0; }
+        if (ntiles == 0 && tile == 0 && threadIdx.x == 0) *next_count = 0;
         return;
     }
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -165,11 +151,6 @@ PT_DEV void scatter_tile(uint32_t tile, const uint32_t *__restrict__ count_ptr, 
     for (uint32_t i = 0; i < wave; i++) wbase += wtot[i];
     const uint32_t my_off = base0 + wbase + inc - c;                  // offset of this lane's word
     if (tile == ntiles - 1 && threadIdx.x == TILE_WORDS - 1) *next_count = my_off + c;
-    if (next_boundary) {
-        const uint32_t bnd = *boundary_ptr < count ? *boundary_ptr : count;
-        if ((bnd >> 6) == w && w < nwords) *next_boundary = my_off + (uint32_t)__popcll(m & ((1ull << (bnd & 63u)) - 1ull));
-        else if ((bnd >> 6) >= nwords && tile == ntiles - 1 && threadIdx.x == TILE_WORDS - 1) *next_boundary = my_off + c;   // everything is below it
-    }
     // cooperative scatter: the wave walks its 64 words
     const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
     const uint32_t w0 = tile * TILE_WORDS + wave * 64u;
@@ -180,7 +161,7 @@ PT_DEV void scatter_tile(uint32_t tile, const uint32_t *__restrict__ count_ptr, 
         if ((jm >> lane) & 1ull) {
             const uint32_t below = (uint32_t)__popcll(jm & ((1ull << lane) - 1ull));
             const uint32_t slot = (w0 + j) * 64u + lane;
-            next_queue[jbase + below] = queue ? queue[slot] : slot + id_base;
+            next_queue[jbase + below] = queue ? queue[slot] : slot;
         }
     }
 }
@@ -190,9 +171,8 @@ __global__ __launch_bounds__(TILE_WORDS) void k_scatter(const uint32_t *__restri
                                                         const uint64_t *__restrict__ alive,
                                                         const uint32_t *__restrict__ tile_sums,
                                                         uint32_t *__restrict__ next_queue,
-                                                        uint32_t *__restrict__ next_count, uint32_t id_base,
-                                                        const uint32_t *__restrict__ boundary_ptr, uint32_t *__restrict__ next_boundary) {
-    scatter_tile(blockIdx.x, count_ptr, queue, alive, tile_sums, next_queue, next_count, id_base, boundary_ptr, next_boundary);
+                                                        uint32_t *__restrict__ next_count) {
+    scatter_tile(blockIdx.x, count_ptr, queue, alive, tile_sums, next_queue, next_count);
 }
 // both compactions of a bounce in one launch: workgroups [0, tiles) compact the survivors into the next queue,
 // [tiles, 2 tiles) the emitted records into the shadow index list
@@ -201,18 +181,14 @@ __global__ __launch_bounds__(TILE_WORDS) void k_scatter2(uint32_t tiles, const u
                                                          const uint64_t *__restrict__ alive, const uint64_t *__restrict__ shadow,
                                                          const uint32_t *__restrict__ tile_sums, const uint32_t *__restrict__ shadow_sums,
                                                          uint32_t *__restrict__ next_queue, uint32_t *__restrict__ next_count,
-                                                         uint32_t *__restrict__ shadow_queue, uint32_t *__restrict__ shadow_count,
-                                                         uint32_t id_base, const uint32_t *__restrict__ boundary_ptr,
-                                                         uint32_t *__restrict__ next_boundary) {
-    if (blockIdx.x < tiles) scatter_tile(blockIdx.x, count_ptr, queue, alive, tile_sums, next_queue, next_count, id_base, boundary_ptr, next_boundary);
+                                                         uint32_t *__restrict__ shadow_queue, uint32_t *__restrict__ shadow_count) {
+    if (blockIdx.x < tiles) scatter_tile(blockIdx.x, count_ptr, queue, alive, tile_sums, next_queue, next_count);
     else scatter_tile(blockIdx.x - tiles, count_ptr, nullptr, shadow, shadow_sums, shadow_queue, shadow_count);
 }
 
 // pt.wgsl:751-761 for the batch's frames in ascending order
-// ... and the radiance is left ZERO: the next batch on these paths starts from pt.wgsl:640's `result = vec3f(0.0)` without a pass of
-// its own (k_raygen used to write it)
 __global__ __launch_bounds__(BLOCK) void k_accumulate(DevBand band, uint32_t frame0, uint32_t n_frames,
-                                                      float *__restrict__ L, uint32_t l_stride, float4 *__restrict__ out) {
+                                                      const float *__restrict__ L, uint32_t l_stride, float4 *__restrict__ out) {
     const uint32_t npix = band.rows * band.width;
     for (uint32_t pix = blockIdx.x * BLOCK + threadIdx.x; pix < npix; pix += gridDim.x * BLOCK) {
         const size_t oi = (size_t)band.row_of(pix / band.width) * band.width + pix % band.width;
@@ -220,8 +196,8 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(DevBand band, uint32_t fra
         for (uint32_t k = 0; k < n_frames; k++) {
             const size_t li = (size_t)k * npix + pix;
             rgb_sc l;
-            if (l_stride == 4u) { const float4 v = reinterpret_cast<const float4 *>(L)[li]; l = rgb_sc{v.x, v.y, v.z}; reinterpret_cast<float4 *>(L)[li] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
-            else { l = reinterpret_cast<const rgb_sc *>(L)[li]; reinterpret_cast<rgb_sc *>(L)[li] = rgb_sc{0.0f, 0.0f, 0.0f}; }
+            if (l_stride == 4u) { const float4 v = reinterpret_cast<const float4 *>(L)[li]; l = rgb_sc{v.x, v.y, v.z}; }
+            else l = reinterpret_cast<const rgb_sc *>(L)[li];
             float cx = min1(l.x, 2.5f), cy = min1(l.y, 2.5f), cz = min1(l.z, 2.5f);
             uint32_t frame = frame0 + k;
             if (frame > 0u) {
@@ -344,9 +320,8 @@ void pt_launch_exact_math(hipStream_t s, int which, unsigned long long *out) {
     hipLaunchKernelGGL(k_exact_math, dim3(256 * 16), dim3(256), 0, s, which, out);
 }
 void pt_launch_raygen(hipStream_t s, int blocks, const ptmi_camera &cam, DevBand band, uint32_t frame0,
-                      uint32_t n_frames, DevPaths p, uint32_t id_base, const uint32_t *count_in, uint32_t *count_out,
-                      uint32_t *boundary_out, uint32_t *queue) {
-    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(BLOCK), 0, s, cam, band, frame0, n_frames, p, id_base, count_in, count_out, boundary_out, queue);
+                      uint32_t n_frames, DevPaths p, uint32_t *count_out) {
+    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(BLOCK), 0, s, cam, band, frame0, n_frames, p, count_out);
 }
 void pt_launch_raygen_list(hipStream_t s, const ptmi_camera &cam, uint32_t n, const uint32_t *xs,
                            const uint32_t *ys, const uint32_t *frames, DevPaths p) {
@@ -355,25 +330,26 @@ void pt_launch_raygen_list(hipStream_t s, const ptmi_camera &cam, uint32_t n, co
 void pt_launch_compact(hipStream_t s, int tiles, const uint32_t *queue, const uint32_t *count,
                        const uint64_t *alive_mask, const uint64_t *shadow_mask, uint32_t *tile_sums,
                        uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_queue, uint32_t *shadow_count,
-                       unsigned long long *stats, uint32_t bounce_a, uint32_t bounce_b, const uint32_t *boundary, uint32_t *next_boundary,
-                       uint32_t id_base, int do_scatter) {
+                       unsigned long long *stats, uint32_t bounce, int do_scatter) {
     uint32_t *shadow_sums = tile_sums + tiles;
     hipLaunchKernelGGL(k_tile_sums, dim3(tiles), dim3(TILE_WORDS), 0, s, count, alive_mask, shadow_mask, tile_sums,
-                       shadow_sums, stats, bounce_a, bounce_b, boundary);
+                       shadow_sums, stats, bounce);
+#ifndef PT_NO_SCATTER2
     if (do_scatter && shadow_mask) {
         hipLaunchKernelGGL(k_scatter2, dim3(2 * tiles), dim3(TILE_WORDS), 0, s, (uint32_t)tiles, count, queue, alive_mask, shadow_mask,
-                           tile_sums, shadow_sums, next_queue, next_count, shadow_queue, shadow_count, id_base, boundary, next_boundary);
+                           tile_sums, shadow_sums, next_queue, next_count, shadow_queue, shadow_count);
         return;
     }
+#endif
     if (do_scatter)
         hipLaunchKernelGGL(k_scatter, dim3(tiles), dim3(TILE_WORDS), 0, s, count, queue, alive_mask, tile_sums,
-                           next_queue, next_count, id_base, boundary, next_boundary);
+                           next_queue, next_count);
     if (shadow_mask)    // slots (not path ids) of the emitted shadow records, ascending
         hipLaunchKernelGGL(k_scatter, dim3(tiles), dim3(TILE_WORDS), 0, s, count, (const uint32_t *)nullptr,
-                           shadow_mask, shadow_sums, shadow_queue, shadow_count, 0u, (const uint32_t *)nullptr, (uint32_t *)nullptr);
+                           shadow_mask, shadow_sums, shadow_queue, shadow_count);
 }
 void pt_launch_accumulate(hipStream_t s, int blocks, DevBand band, uint32_t frame0, uint32_t n_frames,
-                          float *L, uint32_t l_stride, float4 *out) {
+                          const float *L, uint32_t l_stride, float4 *out) {
     hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(BLOCK), 0, s, band, frame0, n_frames, L, l_stride, out);
 }
 void pt_launch_pack_rows(hipStream_t s, int blocks, DevBand band, const float4 *frame, float4 *packed) {

@@ -56,7 +56,6 @@ struct DevScene {
     float ref_root_min[3], ref_root_max[3];
     float safe_origin;          // |o|_inf up to which the boxes' padding covers the rounding of the fused slab test
     unsigned long long *verify_stat;    // += rays whose winner failed its reference leaf's box and were traced again
-    const uint8_t *tri_class;   // per triangle: the kind of its material (shade.hip: the key `shade` sorts a workgroup's segments by); NULL: none
     const DevScene *self;       // this description in device memory (the own-leaf kernels read it from there, not from kernel arguments)
 };
 
@@ -102,17 +101,9 @@ struct DevBand {
     }
 };
 
-// INTERLEAVED BATCHES (ptmi_api.hip ptmi_dispatch). One launch may carry the segments of TWO batches, half a path apart: the survivors of
-// the older batch (at bounce_a) in the queue slots below *boundary, the newer batch (at bounce_b) from there on — the small queues of a
-// batch's last bounces then ride along with the next batch's first ones instead of running the machine half empty. Path ids of the
-// two batches are disjoint (the newer one's start at id_base when its queue is the identity: bounce 0, nothing in front of it).
 struct ShadeParams {
-    uint32_t bounce_a, bounce_b;        // of the segments in slots [0, *boundary) / [*boundary, count)
-    const uint32_t *boundary;
-    uint32_t id_base;                   // queue == NULL: slot i holds path id_base + i
-    uint32_t max_bounces, do_mis;
+    uint32_t bounce, max_bounces, do_mis;
     unsigned long long *stats;          // [1] += next-event samples counted but not traced (zero contribution)
-    uint32_t sort;                      // 1: the segments of a workgroup round are dealt to the lanes by the kind of hit (shade.hip k_shade<SORT>)
     uint32_t emit_records;              // 1: an emissive hit does not add to L here; it leaves a record (SO.w = -2: nothing to trace)
                                         //    that `shadow` adds like an unoccluded light sample — all additions to L then happen in
                                         //    that one kernel, in bounce order, and `shadow` can run beside the next bounce's kernels.
@@ -141,18 +132,14 @@ struct TraverseConfig {
 size_t pt_spill_bytes(int blocks);
 
 // ---- launchers (each enqueues on `s`; grids are persistent, sized by the caller) ----
-// camera rays of a batch into the paths id_base .. id_base + n - 1. count_in == NULL: the batch is alone (*count_out = n, *boundary_out
-// = 0, no queue written: slot i holds path id_base + i); else its ids are appended to `queue` behind the *count_in entries it holds
-// (*boundary_out = *count_in, *count_out = *count_in + n). The radiance is NOT zeroed here: accumulate leaves it zero.
 void pt_launch_raygen(hipStream_t s, int blocks, const ptmi_camera &cam, DevBand band, uint32_t frame0,
-                      uint32_t n_frames, DevPaths p, uint32_t id_base, const uint32_t *count_in, uint32_t *count_out,
-                      uint32_t *boundary_out, uint32_t *queue);
+                      uint32_t n_frames, DevPaths p, uint32_t *count_out);
 void pt_launch_raygen_list(hipStream_t s, const ptmi_camera &cam, uint32_t n, const uint32_t *xs,
                            const uint32_t *ys, const uint32_t *frames, DevPaths p);
 void pt_launch_extend(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, DevPaths p,
-                      const uint32_t *queue, const uint32_t *count, float2 *hits, uint32_t id_base = 0);
+                      const uint32_t *queue, const uint32_t *count, float2 *hits);
 void pt_launch_extend_own(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, DevPaths p,
-                          const uint32_t *queue, const uint32_t *count, float2 *hits, uint32_t id_base = 0);        // traverse_own.hip
+                          const uint32_t *queue, const uint32_t *count, float2 *hits);        // traverse_own.hip
 // (u, v) of n hit records, rebuilt the way `shade` does it (debug entry point of the parity tests)
 void pt_launch_hit_uv(hipStream_t s, uint32_t n, const DevScene &sc, DevPaths p, const float2 *hits, float2 *uv);
 // shadow_queue: slots of the shadow records to trace (NULL = slots 0..count-1), count = their number
@@ -169,15 +156,12 @@ void pt_launch_shade_fast(hipStream_t s, int blocks, const DevScene &sc, DevPath
 // ordered stream compaction of the survivors: masks -> next queue + its count, plus statistics
 // (tiles = ceil(capacity / pt_compact_tile_slots()) + 1: one workgroup per tile of ballot words)
 uint32_t pt_compact_tile_slots(void);
-// boundary / bounce_a / bounce_b / id_base: see ShadeParams. *next_boundary = survivors among the slots below *boundary.
 void pt_launch_compact(hipStream_t s, int tiles, const uint32_t *queue, const uint32_t *count,
                        const uint64_t *alive_mask, const uint64_t *shadow_mask, uint32_t *tile_sums,
                        uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_queue, uint32_t *shadow_count,
-                       unsigned long long *stats, uint32_t bounce_a, uint32_t bounce_b, const uint32_t *boundary, uint32_t *next_boundary,
-                       uint32_t id_base, int do_scatter);
-// folds the batch's radiance into the frame and leaves it ZERO for the batch that uses these paths next
+                       unsigned long long *stats, uint32_t bounce, int do_scatter);
 void pt_launch_accumulate(hipStream_t s, int blocks, DevBand band, uint32_t frame0, uint32_t n_frames,
-                          float *L, uint32_t l_stride, float4 *out);
+                          const float *L, uint32_t l_stride, float4 *out);
 void pt_launch_blit(hipStream_t s, int blocks, uint32_t W, uint32_t H, const float4 *color, float4 *out_f32,
                     uint32_t *out_rgba8);
 // a device's rows of the frame <-> a contiguous buffer (ptmi_multi_gather)

@@ -29,8 +29,7 @@ constexpr size_t kMaxPendingEvents = 4096;        // a caller that never synchro
 
 // The buffers of the wavefront batch in flight, and the second stream that lets `shadow` run beside the next bounce.
 struct Lane {
-    size_t cap = 0;                                    // queue slots (hit / shadow records, queues, ballot words)
-    size_t cap_paths = 0;                              // path ids (ray state, radiance): 2 batches' worth when batches are interleaved
+    size_t cap = 0;
     DevPaths paths{};
     float2 *hits = nullptr;
     DevShadow sh[2]{};                                 // shadow records, double-buffered by bounce parity (overlap)
@@ -57,7 +56,6 @@ struct ptmi_ctx {
     void *d_tris = nullptr, *d_mats = nullptr, *d_lights = nullptr, *d_atlas = nullptr;
     float4 *d_wnodes = nullptr, *d_tripos = nullptr, *d_fast_wnodes = nullptr;
     float4 *d_own_tripos = nullptr, *d_leafbox = nullptr;
-    uint8_t *d_tri_class = nullptr;
     DevScene *d_scene = nullptr;                       // sc in device memory (DevScene::self), rewritten whenever sc changes               // own leaves: leaf-ordered triangle images, per-triangle reference leaf boxes
     uint4 *d_qnodes = nullptr; uint32_t *d_leaf_stream = nullptr;        // quantised image of the rebuilt hierarchy (global variant)
     DevScene sc{};
@@ -84,10 +82,7 @@ struct ptmi_ctx {
 namespace {
 
 constexpr int kStatsWords = 8 + 64;
-// ctx->counts: per iteration t (ring of 16) the queue length as compaction left it [t % 16], after a batch was appended [16 + t % 16]
-// and the boundary between the two batches in it [32 + t % 16]; the shadow-queue lengths by parity [kShadowCount ..]
-constexpr int kCountWords = 80;
-constexpr int kShadowCount = 72;
+constexpr int kShadowCount = 72;          // slot of the shadow-queue length in ctx->counts (80 words)
 constexpr size_t kLdsMax = 160 * 1024;
 int fail(const ptmi_ctx *c, int code, const char *fmt, ...) {
     char buf[512];
@@ -176,7 +171,7 @@ void free_batch(Lane &ln) {
     dfree(ln.hits);
     for (int k = 0; k < 2; k++) { dfree(ln.sh[k].SO); ln.sh[k].SD = nullptr; ln.sh[k].SC = nullptr; dfree(ln.sq[k]); }
     dfree(ln.queue[0]); dfree(ln.queue[1]); dfree(ln.alive); dfree(ln.shadowm); dfree(ln.word_off); dfree(ln.d_occ);
-    ln.cap = 0; ln.cap_paths = 0;
+    ln.cap = 0;
 }
 
 // everything the library has in flight, on every stream it owns
@@ -190,14 +185,11 @@ hipError_t sync_all(ptmi_ctx *c) {
 // bytes of device memory a path of a batch takes in ensure_capacity (state 56 + hit 8 + 2 x (record 44 + index 4) + 2 queues + masks)
 constexpr size_t kBytesPerPath = 16 + 16 + 8 + 16 + 8 + 2 * (16 + 16 + sizeof(rgb_sc) + 4) + 2 * 4 + 1 + 1;
 
-int ensure_capacity(ptmi_ctx *c, Lane &ln, size_t n, size_t n_paths = 0) {
-    if (n_paths < n) n_paths = n;
-    if (n <= ln.cap && n_paths <= ln.cap_paths) return PTMI_OK;
-    n = std::max(n, ln.cap); n_paths = std::max(n_paths, ln.cap_paths);
+int ensure_capacity(ptmi_ctx *c, Lane &ln, size_t n) {
+    if (n <= ln.cap) return PTMI_OK;
     HIP_TRY(c, sync_all(c));
     free_batch(ln);
     size_t cap = (n + 1023) & ~(size_t)1023;
-    const size_t pcap = (n_paths + 1023) & ~(size_t)1023;
     size_t words = cap / 64 + 1;
     size_t tiles = cap / pt_compact_tile_slots() + 2;
     c->alloc_oom = false;
@@ -206,13 +198,8 @@ int ensure_capacity(ptmi_ctx *c, Lane &ln, size_t n, size_t n_paths = 0) {
 #define ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc(&(ptr), (bytes)); if (e_ != hipSuccess) { \
         c->alloc_oom = e_ == hipErrorOutOfMemory; free_batch(ln); (void)hipGetLastError(); \
         return fail(c, PTMI_E_HIP, "hipMalloc of %zu bytes for a batch of %zu paths failed: %s", (size_t)(bytes), cap, hipGetErrorString(e_)); } } while (0)
-    ALLOC(ln.paths.O, pcap * 16); ALLOC(ln.paths.D, pcap * 16);
-    ALLOC(ln.paths.C, pcap * 8); ALLOC(ln.paths.L, pcap * 16);      // room for either stride
-    {   // the radiance starts at zero and every accumulate leaves it so (pipeline.hip k_accumulate). On the context's stream: the
-        // streams are non-blocking, a memset on the default stream would not be ordered before their kernels
-        hipError_t e_ = hipMemsetAsync(ln.paths.L, 0, pcap * 16, c->stream);
-        if (e_ != hipSuccess) { free_batch(ln); return fail(c, PTMI_E_HIP, "hipMemset failed: %s", hipGetErrorString(e_)); }
-    }
+    ALLOC(ln.paths.O, cap * 16); ALLOC(ln.paths.D, cap * 16);
+    ALLOC(ln.paths.C, cap * 8); ALLOC(ln.paths.L, cap * 16);      // room for either stride
     ALLOC(ln.hits, cap * 8);
     for (int k = 0; k < 2; k++) {
         ALLOC(ln.sh[k].SO, cap * (16 + 16 + sizeof(rgb_sc)));
@@ -224,7 +211,7 @@ int ensure_capacity(ptmi_ctx *c, Lane &ln, size_t n, size_t n_paths = 0) {
     ALLOC(ln.word_off, 2 * tiles * 4);
     ALLOC(ln.d_occ, cap);
 #undef ALLOC
-    ln.cap = cap; ln.cap_paths = pcap;
+    ln.cap = cap;
     return PTMI_OK;
 }
 
@@ -247,7 +234,6 @@ struct Built {
     PtOwnTree own_tree;
     std::vector<uint4> own_qnodes;           // quantised nodes of own_tree (empty: a 16-bit grid does not resolve this scene)
     std::vector<float4> leafbox;             // 2 float4 per triangle (original index): its reference leaf's box
-    std::vector<uint8_t> tri_class;          // per triangle: kind of its material (shade.hip N_CLASSES: 1 emissive, 2 transmissive, 3 metallic, 4 diffuse)
 };
 
 #ifndef PT_LEAVES_DEFAULT
@@ -359,9 +345,7 @@ int build_image(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_
         const uint32_t k_max = c->opt.leaf_tris ? c->opt.leaf_tris : (uint32_t)PT_LEAF_TRIS_DEFAULT;
         // small scenes: at most 14 levels, so that a lane's whole node stack fits the 15 LDS entries of two workgroups per CU
         const uint32_t limit = which.size() <= 2048 ? 14u : 60u;
-        const auto t_own = std::chrono::steady_clock::now();
         b.own = pt_build_own_tree(tris, which, k_max, limit, b.own_tree);
-        const auto t_q = std::chrono::steady_clock::now();
         if (b.own) {
             float qo[3], qs[3];
             if (pt_quantize_nodes(b.own_tree.wnodes, b.own_qnodes, qo, qs, PT_QCACHE_NODES, b.q_top))
@@ -371,10 +355,6 @@ int build_image(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_
             b.leafbox.clear();
         }
         b.tree_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (std::getenv("PTMI_TREE_DEBUG"))
-            std::fprintf(stderr, "own image: %.1f ms (lists %.1f, tree %.1f, quantised nodes %.1f)\n", b.tree_ms,
-                         std::chrono::duration<double, std::milli>(t_own - t0).count(), std::chrono::duration<double, std::milli>(t_q - t_own).count(),
-                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_q).count());
     }
     if (nested && leaves.size() >= 2 && !c->opt.keep_reference_tree && !b.own) {
         const auto t0 = std::chrono::steady_clock::now();
@@ -617,7 +597,7 @@ int ptmi_create(int device_ordinal, ptmi_ctx **out) {
 #endif
         for (hipEvent_t *e : {&ln.ev_ready, &ln.ev_shadow[0], &ln.ev_shadow[1]})
             ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipMalloc(&ln.counts, kCountWords * sizeof(uint32_t)) == hipSuccess;
+        ok = ok && hipMalloc(&ln.counts, 80 * sizeof(uint32_t)) == hipSuccess;
         if (!ok) { ptmi_destroy(c); return fail(nullptr, PTMI_E_HIP, "stream / event creation failed"); }
     }
     if (hipMalloc(&c->d_stats, kStatsWords * sizeof(unsigned long long)) != hipSuccess ||
@@ -644,7 +624,7 @@ int ptmi_destroy(ptmi_ctx *c) {
         if (ln.side) (void)hipStreamDestroy(ln.side);
     }
     dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_atlas); dfree(c->d_wnodes); dfree(c->d_tripos);
-    dfree(c->d_fast_wnodes); dfree(c->d_qnodes); dfree(c->d_leaf_stream); dfree(c->d_own_tripos); dfree(c->d_leafbox); dfree(c->d_tri_class);
+    dfree(c->d_fast_wnodes); dfree(c->d_qnodes); dfree(c->d_leaf_stream); dfree(c->d_own_tripos); dfree(c->d_leafbox);
     dfree(c->d_out_own); dfree(c->d_stats); dfree(c->d_scene); dfree(c->d_blit_f32); dfree(c->d_blit_u8);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -681,18 +661,6 @@ PtPrepared *pt_prepare_scene(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt
     int rc = build_image(c, tris, nt, nodes, nn, p->b);
     if (rc) { delete p; return bad(rc); }
     p->tris = tris; p->nt = nt; p->mats = mats; p->nm = nm; p->lights = lights; p->nl = nl;
-    p->b.tri_class.resize(nt);
-    for (uint32_t i = 0; i < nt; i++) {              // the key `shade` sorts by: which branch of pt.wgsl:646-705 a hit on this triangle takes
-        const uint32_t mi = tris[i].material_index;
-        uint8_t k = 4;
-        if (mi < nm) {
-            const ptmi_material &m = mats[mi];
-            if (m.emission[0] > 0.0f || m.emission[1] > 0.0f || m.emission[2] > 0.0f) k = 1;
-            else if (m.transmission > 0.0f) k = 2;
-            else if (m.metallic >= 0.5f) k = 3;
-        }
-        p->b.tri_class[i] = k;
-    }
     p->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
     p->opt = c->opt;
     *rc_out = PTMI_OK;
@@ -714,7 +682,7 @@ int pt_install_scene(ptmi_ctx *c, const PtPrepared *prep) {
     const auto t_copy = clk::now();
     void *n_tris = nullptr, *n_mats = nullptr, *n_lights = nullptr;
     float4 *n_wnodes = nullptr, *n_tripos = nullptr, *n_fast = nullptr, *n_own_tripos = nullptr, *n_leafbox = nullptr;
-    uint4 *n_qnodes = nullptr; uint32_t *n_stream = nullptr; uint8_t *n_class = nullptr;
+    uint4 *n_qnodes = nullptr; uint32_t *n_stream = nullptr;
     const bool own = b.own;
     const std::vector<uint4> &qn = own ? b.own_qnodes : b.qnodes;
     const bool quant = !qn.empty();
@@ -734,18 +702,16 @@ int pt_install_scene(ptmi_ctx *c, const PtPrepared *prep) {
     if (e == hipSuccess && fast) e = up(reinterpret_cast<void **>(&n_fast), walk.data(), walk.size() * 16);
     if (e == hipSuccess && own) e = up(reinterpret_cast<void **>(&n_own_tripos), b.own_tree.tripos.data(), b.own_tree.tripos.size() * 16);
     if (e == hipSuccess && own) e = up(reinterpret_cast<void **>(&n_leafbox), b.leafbox.data(), b.leafbox.size() * 16);
-    if (e == hipSuccess) e = up(reinterpret_cast<void **>(&n_class), b.tri_class.data(), b.tri_class.size());
     if (e == hipSuccess && quant) e = up(reinterpret_cast<void **>(&n_qnodes), qn.data(), qn.size() * 16);
     if (e == hipSuccess && quant && !own) e = up(reinterpret_cast<void **>(&n_stream), b.leaf_stream.data(), b.leaf_stream.size() * 4);
     if (e != hipSuccess) {
         dfree(n_tris); dfree(n_mats); dfree(n_lights); dfree(n_wnodes); dfree(n_tripos); dfree(n_fast); dfree(n_qnodes); dfree(n_stream);
-        dfree(n_own_tripos); dfree(n_leafbox); dfree(n_class);
+        dfree(n_own_tripos); dfree(n_leafbox);
         return fail(c, PTMI_E_HIP, "scene upload failed: %s (the previous scene, if any, is still in place)", hipGetErrorString(e));
     }
     HIP_TRY(c, sync_all(c));                  // nothing in flight reads the old buffers any more
     dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_wnodes); dfree(c->d_tripos); dfree(c->d_fast_wnodes);
-    dfree(c->d_qnodes); dfree(c->d_leaf_stream); dfree(c->d_own_tripos); dfree(c->d_leafbox); dfree(c->d_tri_class);
-    c->d_tri_class = n_class;
+    dfree(c->d_qnodes); dfree(c->d_leaf_stream); dfree(c->d_own_tripos); dfree(c->d_leafbox);
     c->d_qnodes = n_qnodes; c->d_leaf_stream = n_stream;
     c->d_tris = n_tris; c->d_mats = n_mats; c->d_lights = n_lights;
     c->d_wnodes = n_wnodes; c->d_tripos = n_tripos; c->d_fast_wnodes = n_fast;
@@ -771,7 +737,6 @@ int pt_install_scene(ptmi_ctx *c, const PtPrepared *prep) {
     s.own = own ? 1u : 0u;
     s.n_own_tris = own ? (uint32_t)(b.own_tree.tripos.size() / 3) : 0u;
     s.tri_leafbox = c->d_leafbox;
-    s.tri_class = c->d_tri_class;
     s.safe_origin = own ? b.own_tree.safe_origin : 0.0f;
     s.verify_stat = c->d_stats + 4;
     s.self = c->d_scene;
@@ -839,10 +804,9 @@ int ptmi_set_options(ptmi_ctx *c, const ptmi_options *o) {
         return fail(c, PTMI_E_INVALID, "tile_part %u is not below tile_parts %u", o->tile_part, o->tile_parts);
     if (o->perf_mode > 1) return fail(c, PTMI_E_INVALID, "unknown perf_mode %u", o->perf_mode);
     if (o->overlap > 2) return fail(c, PTMI_E_INVALID, "unknown overlap %u", o->overlap);
-    if (o->reserved_a || o->reserved_b[0] || o->reserved_b[1] || o->reserved_b[2] || o->reserved_b[3])
+    if (o->reserved_a || o->reserved_b[0] || o->reserved_b[1] || o->reserved_b[2] || o->reserved_b[3] || o->reserved[0])
         return fail(c, PTMI_E_INVALID, "a reserved option word is not zero (ABI <= 3's ray_sort / worklist / tails / state / pipeline are gone: "
                     "start from ptmi_get_options)");
-    if (o->shade_sort > 2) return fail(c, PTMI_E_INVALID, "unknown shade_sort %u", o->shade_sort);
     if (o->leaves > 2) return fail(c, PTMI_E_INVALID, "unknown leaves %u", o->leaves);
     if (o->leaf_tris > PT_LEAF_MAX_TRIS) return fail(c, PTMI_E_INVALID, "leaf_tris %u above %u", o->leaf_tris, PT_LEAF_MAX_TRIS);
     if (o->tree_builder > 2) return fail(c, PTMI_E_INVALID, "unknown tree_builder %u", o->tree_builder);
@@ -880,8 +844,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const uint64_t held = (uint64_t)ln.cap * kBytesPerPath;
             const uint64_t room = (uint64_t)((double)(free_b + held) * 0.9);
-            const uint64_t two = n_frames > F ? 2u : 1u;         // several batches: two are resident at a time (interleaved batches, below)
-            F = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(F, room / (npix * kBytesPerPath * two)));
+            F = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(F, room / (npix * kBytesPerPath)));
         }
     }
     F = std::min(F, n_frames);
@@ -891,28 +854,12 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     // path's sum is formed in the same order as without it. Record buffers alternate by bounce parity; shade(b) waits for
     // shadow(b - 2), the end of the batch for the last one.
     const bool side = nee && c->opt.overlap != 0;
-    const uint32_t maxb = c->opt.max_bounces;
-    // INTERLEAVED BATCHES. A dispatch of several batches starts batch k + 1 when batch k has run half its bounces (s = ceil(max_bounces
-    // / 2) iterations later) and carries both through the same launches: the queue of an iteration holds the survivors of the older
-    // batch in front of the newer one's, `shade` and the statistics tell them apart by the slot (pt_device.h ShadeParams), every other
-    // kernel does not care which bounce a ray is on. The last bounces of a batch — a tenth of the rays, which by themselves leave the
-    // machine half empty (18 % of a Cornell step for 7 % of its segments) — then share their launches with the next batch's first
-    // ones. Path ids of consecutive batches alternate between two halves of the state buffers. Every path still sees exactly its own
-    // sequence of operations, and `shadow` its additions in bounce order: same bits (every multi-batch parity test runs this loop).
-    const uint32_t n_batches = (n_frames + F - 1) / F;
-#ifndef PT_INTERLEAVE_DEFAULT
-#define PT_INTERLEAVE_DEFAULT 1
-#endif
-    const bool want_inter = std::getenv("PTMI_INTERLEAVE") ? std::atoi(std::getenv("PTMI_INTERLEAVE")) != 0 : PT_INTERLEAVE_DEFAULT != 0;   // (A/B switch)
-    const bool inter = want_inter && n_batches > 1 && maxb >= 2;
-    const uint32_t shift = inter ? (maxb + 1) / 2 : maxb;       // batch k enters at iteration k * shift
-    if (npix * F > 0x7FFFFF00ull) return fail(c, PTMI_E_UNSUPPORTED, "batch of %llu paths exceeds 2^31", (unsigned long long)(npix * F));
+    if (npix * F > 0xFFFFFF00ull) return fail(c, PTMI_E_UNSUPPORTED, "batch of %llu paths exceeds 2^32", (unsigned long long)(npix * F));
     const TraverseConfig cfg0 = traverse_config(c, true), cfg_shadow0 = traverse_config(c, false);
     if (c->opt.traversal == PTMI_TRAVERSAL_LDS && cfg0.variant != PT_VARIANT_LDS && cfg0.variant != PT_VARIANT_OWN_LDS && cfg0.variant != PT_VARIANT_OWN_QLDS)
         return fail(c, PTMI_E_UNSUPPORTED, "scene needs %zu B of LDS plus the stack; it does not fit in %zu B", c->lds_scene_bytes, kLdsMax);
     for (;;) {
-        const size_t n = (size_t)(npix * F) * (inter ? 2 : 1);
-        rc = ensure_capacity(c, ln, n, n);
+        rc = ensure_capacity(c, ln, (size_t)(npix * F));
         if (rc == PTMI_OK) break;
         // out of device memory with a batch size the library chose: halve it and try again (hipMemGetInfo is a snapshot; another
         // context may have allocated since). A size the caller asked for fails loudly.
@@ -929,11 +876,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     c->st.extend_variant = (uint32_t)cfg0.variant * 10u + (uint32_t)cfg0.wgs_per_cu;
     c->st.shadow_variant = (uint32_t)cfg_shadow0.variant * 10u + (uint32_t)cfg_shadow0.wgs_per_cu;
     c->st.frames_per_batch_used = F;
-    c->st.interleaved = inter ? 1u : 0u;
     c->st.radiance_stride_bytes = 4u * (PT_L_STRIDE ? (uint32_t)PT_L_STRIDE : ((walks_memory_quantised(cfg0) || walks_memory_quantised(cfg_shadow0)) ? 4u : 3u));
-    {   // (a dispatch whose radiance stride differs from the last one's must not find the other layout's zeros half-overwritten: L is
-        // all zeros between dispatches either way)
-    }
     const int blocks = c->n_cu * 8;
 #ifndef PT_SHADE_WGS_PER_CU
 #define PT_SHADE_WGS_PER_CU 16
@@ -941,11 +884,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
     // 256-thread workgroups of the grid-stride shade kernel. Config 1, five interleaved runs each (Msamples/s): 8 per CU 9 247,
     // 16: 9 362, 32: 9 303, 64: 8 929 (run-to-run +-130); config 3 +-0.
     const int shade_blocks = c->n_cu * PT_SHADE_WGS_PER_CU;
-#ifndef PT_SHADE_SORT_DEFAULT
-#define PT_SHADE_SORT_DEFAULT 1        /* what ptmi_options.shade_sort = 0 means: 1 off, 2 on (measured: profiles/README.md) */
-#endif
-    const bool shade_sort = (c->opt.shade_sort ? c->opt.shade_sort : (uint32_t)PT_SHADE_SORT_DEFAULT) == 2u;
-    c->st.shade_sort_used = shade_sort ? 2u : 1u;
+    const uint32_t maxb = c->opt.max_bounces;
     const bool t1 = c->opt.timing >= 1, t2 = c->opt.timing >= 2, t3 = c->opt.timing >= 3;
     {
         Timed td(c, 0, t1);
@@ -957,68 +896,44 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
         if (cfg_shadow.wants_spill && !cfg_shadow.spill) cfg_shadow.spill = ln.d_spill_side;
         ln.paths.l_stride = c->st.radiance_stride_bytes / 4u;
         const DevPaths bp = ln.paths;
-        const uint32_t batch_paths = (uint32_t)(npix * F);
-        auto frames_of = [&](uint32_t k) { return std::min(F, n_frames - k * F); };
-        auto base_of = [&](uint32_t k) { return inter ? (k & 1u) * batch_paths : 0u; };
-        auto fold = [&](uint32_t k, hipStream_t st) {        // pt.wgsl:751-761 for batch k's frames, in frame order; leaves its radiance zero
-            Timed t(c, 6, t3, st);
-            pt_launch_accumulate(st, blocks, band, cam->frame_index + k * F, frames_of(k), bp.L + (size_t)base_of(k) * bp.l_stride, bp.l_stride, c->d_out);
-        };
-        const uint32_t total_iters = (n_batches - 1) * shift + maxb;
-        int cur = 0;                                          // which queue buffer holds this iteration's queue
-        bool side_used = false;
-        for (uint32_t t = 0; t < total_iters; t++) {
-            const uint32_t k1 = t / shift, k0 = k1 - 1u;     // the two batches that can be in flight: the newer and the older one
-            const bool act1 = k1 < n_batches && t - k1 * shift < maxb, act0 = k1 >= 1u && t - k0 * shift < maxb;
-            uint32_t bounce_b = act1 ? t - k1 * shift : 0u, bounce_a = act0 ? t - k0 * shift : bounce_b;
-            if (!act1) bounce_b = bounce_a;                  // one batch only: both names mean its bounce, wherever the boundary is
-            uint32_t *const cw_pre = &ln.counts[t % 16u], *const cw_app = &ln.counts[16u + t % 16u], *const bw = &ln.counts[32u + t % 16u];
-            const uint32_t *count = cw_pre;
-            const uint32_t *q = ln.queue[cur];
-            uint32_t id_base = 0;
-            if (act1 && bounce_b == 0u) {                    // batch k1 enters: alone (identity queue, not stored), or behind the older batch's survivors
-                Timed tr(c, 4, t3, ms);
-                id_base = base_of(k1);
-                pt_launch_raygen(ms, blocks, *cam, band, cam->frame_index + k1 * F, frames_of(k1), bp, id_base, act0 ? cw_pre : nullptr, cw_app, bw,
-                                 act0 ? ln.queue[cur] : nullptr);
-                count = cw_app;
-                if (!act0) q = nullptr;
+        for (uint32_t f0 = 0; f0 < n_frames; f0 += F) {
+            const uint32_t fb = std::min(F, n_frames - f0);
+            const uint32_t frame0 = cam->frame_index + f0;
+            { Timed t(c, 4, t3, ms); pt_launch_raygen(ms, blocks, *cam, band, frame0, fb, bp, &ln.counts[0]); }
+            int cur = 0;
+            for (uint32_t b = 0; b < maxb; b++) {
+                const uint32_t *q = b == 0 ? nullptr : ln.queue[cur];      // bounce 0: slot i holds path i
+                const int par = side ? (int)(b & 1u) : 0;
+                const ShadeParams shp{b, maxb, c->opt.do_mis, c->d_stats, side ? 1u : 0u};
+                { Timed t(c, 1, t2, ms); (c->sc.own ? pt_launch_extend_own : pt_launch_extend)(ms, blocks, cfg, c->sc, bp, q, &ln.counts[b], ln.hits); }
+                const bool last = b + 1 == maxb;
+                if (side && b >= 2) HIP_TRY(c, hipStreamWaitEvent(ms, ln.ev_shadow[par], 0));      // its records are read
+                { Timed t(c, 2, t3, ms);
+                  (c->opt.perf_mode ? pt_launch_shade_fast : pt_launch_shade)(
+                      ms, shade_blocks, c->sc, bp, q, &ln.counts[b], ln.hits, ln.sh[par], ln.alive, ln.shadowm, shp); }
+                { Timed t(c, 5, t3, ms);
+                  pt_launch_compact(ms, tiles, q, &ln.counts[b], ln.alive, nee ? ln.shadowm : nullptr,
+                                    ln.word_off, ln.queue[cur ^ 1], &ln.counts[b + 1], ln.sq[par], &ln.counts[kShadowCount + par],
+                                    c->d_stats, b, last ? 0 : 1); }
+                if (side) {
+                    HIP_TRY(c, hipEventRecord(ln.ev_ready, ms));
+                    HIP_TRY(c, hipStreamWaitEvent(ss, ln.ev_ready, 0));
+                    { Timed t(c, 3, t3, ss);
+                      (c->sc.own ? pt_launch_shadow_own : pt_launch_shadow)(ss, blocks, cfg_shadow, c->sc, bp, ln.sh[par], ln.sq[par],
+                                                                            &ln.counts[kShadowCount + par], nullptr); }
+                    HIP_TRY(c, hipEventRecord(ln.ev_shadow[par], ss));
+                } else if (nee) {
+                    Timed t(c, 3, t3, ms);
+                    (c->sc.own ? pt_launch_shadow_own : pt_launch_shadow)(ms, blocks, cfg_shadow, c->sc, bp, ln.sh[0], ln.sq[0], &ln.counts[kShadowCount], nullptr);
+                }
+                cur ^= 1;
             }
-            const int par = side ? (int)(t & 1u) : 0;
-            const ShadeParams shp{bounce_a, bounce_b, bw, id_base, maxb, c->opt.do_mis, c->d_stats,
-                                  (shade_sort && bounce_a >= 1u && bounce_b >= 1u) ? 1u : 0u, side ? 1u : 0u};
-            { Timed tt(c, 1, t2, ms); (c->sc.own ? pt_launch_extend_own : pt_launch_extend)(ms, blocks, cfg, c->sc, bp, q, count, ln.hits, id_base); }
-            if (side && t >= 2) HIP_TRY(c, hipStreamWaitEvent(ms, ln.ev_shadow[par], 0));      // its records are read
-            { Timed tt(c, 2, t3, ms);
-              (c->opt.perf_mode ? pt_launch_shade_fast : pt_launch_shade)(
-                  ms, shade_blocks, c->sc, bp, q, count, ln.hits, ln.sh[par], ln.alive, ln.shadowm, shp); }
-            const bool more = (act0 && bounce_a + 1u < maxb) || (act1 && t - k1 * shift + 1u < maxb);      // a batch goes on to iteration t + 1
-            { Timed tt(c, 5, t3, ms);
-              pt_launch_compact(ms, tiles, q, count, ln.alive, nee ? ln.shadowm : nullptr,
-                                ln.word_off, ln.queue[cur ^ 1], &ln.counts[(t + 1u) % 16u], ln.sq[par], &ln.counts[kShadowCount + par],
-                                c->d_stats, bounce_a, bounce_b, bw, &ln.counts[32u + (t + 1u) % 16u], id_base, more ? 1 : 0); }
+            // all additions to L are in before it is folded
             if (side) {
-                HIP_TRY(c, hipEventRecord(ln.ev_ready, ms));
-                HIP_TRY(c, hipStreamWaitEvent(ss, ln.ev_ready, 0));
-                { Timed tt(c, 3, t3, ss);
-                  (c->sc.own ? pt_launch_shadow_own : pt_launch_shadow)(ss, blocks, cfg_shadow, c->sc, bp, ln.sh[par], ln.sq[par],
-                                                                        &ln.counts[kShadowCount + par], nullptr); }
-                HIP_TRY(c, hipEventRecord(ln.ev_shadow[par], ss));
-                side_used = true;
-            } else if (nee) {
-                Timed tt(c, 3, t3, ms);
-                (c->sc.own ? pt_launch_shadow_own : pt_launch_shadow)(ms, blocks, cfg_shadow, c->sc, bp, ln.sh[0], ln.sq[0], &ln.counts[kShadowCount], nullptr);
+                HIP_TRY(c, hipStreamWaitEvent(ms, ln.ev_shadow[(maxb - 1) & 1u], 0));
+                if (maxb >= 2) HIP_TRY(c, hipStreamWaitEvent(ms, ln.ev_shadow[maxb & 1u], 0));
             }
-            // a batch whose last bounce this was is folded into the frame — behind the shadow kernel that made its last additions, on that
-            // kernel's stream: the main stream goes on with the next iteration (the next batch on these paths does not touch the radiance
-            // before ITS first shadow kernel, which follows the fold on the same stream)
-            if (act0 && bounce_a + 1u == maxb) fold(k0, ss);
-            if (act1 && t - k1 * shift + 1u == maxb) fold(k1, ss);
-            cur ^= 1;
-        }
-        if (side_used) {                                      // the caller's stream sees the finished frame
-            HIP_TRY(c, hipEventRecord(ln.ev_ready, ss));
-            HIP_TRY(c, hipStreamWaitEvent(ms, ln.ev_ready, 0));
+            { Timed t(c, 6, t3, ms); pt_launch_accumulate(ms, blocks, band, frame0, fb, bp.L, bp.l_stride, c->d_out); }
         }
     }
     HIP_TRY(c, hipGetLastError());
@@ -1197,7 +1112,7 @@ int ptmi_debug_intersect(ptmi_ctx *c, uint32_t n, const float *o3, const float *
     if (cfg.wants_spill && !ln.d_spill) HIP_TRY(c, hipMalloc(&ln.d_spill, pt_spill_bytes(c->n_cu * 8)));
     cfg.spill = ln.d_spill;
     c->st.extend_variant = (uint32_t)cfg.variant * 10u + (uint32_t)cfg.wgs_per_cu;
-    (c->sc.own ? pt_launch_extend_own : pt_launch_extend)(c->stream, c->n_cu * 8, cfg, c->sc, ln.paths, nullptr, &ln.counts[0], ln.hits, 0u);
+    (c->sc.own ? pt_launch_extend_own : pt_launch_extend)(c->stream, c->n_cu * 8, cfg, c->sc, ln.paths, nullptr, &ln.counts[0], ln.hits);
     // (u, v) are not part of the hit record: rebuilt exactly as `shade` rebuilds them (into the C stream, unused here)
     pt_launch_hit_uv(c->stream, n, c->sc, ln.paths, ln.hits, ln.paths.C);
     std::vector<float2> h(n), uv(n);

@@ -291,55 +291,18 @@ constexpr int SBLOCK = 256;
 #define PT_SHADE_ATTR
 #endif
 
-// SORT (ptmi_options.shade_sort, bounces >= 1): the 256 segments a workgroup shades in one round are dealt to its lanes by the KIND of
-// hit — miss, emissive material, transmissive, metallic, diffuse (DevScene::tri_class, one byte per triangle, from the material's factors) —
-// so that a wave runs one of the bounce loop's branches (pt.wgsl:646-705: miss / emission / next-event estimation on or off / the three
-// lobes of sampleBSDF) instead of all of them: camera rays of one wave hit one material, but from bounce 1 on a wave mixes everything
-// and issues 1 100 - 1 200 instructions per 64 segments at 0.62 - 0.72 of its lanes (bounce 0: 580 at 0.88). A counting sort over the
-// workgroup (ballots + popcounts per wave, wave totals through LDS); every lane still computes its own segment with the same
-// operations, results go to the segment's own slot, and the ballot words are rebuilt in slot order: nothing downstream can tell.
-constexpr int N_CLASSES = 6;              // 0 miss, 1 emissive, 2 transmissive, 3 metallic, 4 diffuse, 5 beyond the queue's end
-template <bool SORT>
 __global__ __launch_bounds__(SBLOCK) PT_SHADE_ATTR void k_shade(DevScene sc, DevPaths P, const uint32_t *__restrict__ queue,
                                                   const uint32_t *__restrict__ count_ptr,
                                                   const float2 *__restrict__ hits, DevShadow S,
                                                   uint64_t *__restrict__ alive_mask,
                                                   uint64_t *__restrict__ shadow_mask, ShadeParams sp) {
-    __shared__ uint32_t s_cnt[SBLOCK / 64][N_CLASSES];
-    __shared__ uint16_t s_perm[SBLOCK];
-    __shared__ uint8_t s_flags[SBLOCK];
     const uint32_t count = *count_ptr;
-    const uint32_t boundary = *sp.boundary;   // slots below it: the older batch (bounce_a); from it on: the newer one (bounce_b)
     uint32_t n_skipped = 0, n_emitted = 0;  // lane 0 of each wave: one atomic per wave at the end
     for (uint32_t base = blockIdx.x * SBLOCK; base < count; base += gridDim.x * SBLOCK) {
-        uint32_t i = base + threadIdx.x;
-        if (SORT) {
-            const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-            uint32_t cls = N_CLASSES - 1;
-            if (i < count) {
-                const float2 h = hits[i];
-                const uint32_t tri = __float_as_uint(h.y);
-                cls = h.x < 0.0f ? 0u : (tri < sc.n_tris ? (uint32_t)sc.tri_class[tri] : 4u);
-            }
-            uint32_t my_rank = 0;
-            for (uint32_t c = 0; c < (uint32_t)N_CLASSES; c++) {
-                const uint64_t m = __ballot(cls == c);
-                if (cls == c) my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (lane == 0u) s_cnt[wave][c] = (uint32_t)__popcll(m);
-            }
-            __syncthreads();
-            uint32_t dest = my_rank;
-            for (uint32_t c = 0; c < (uint32_t)N_CLASSES; c++)
-                for (uint32_t w = 0; w < SBLOCK / 64; w++)
-                    if (c < cls || (c == cls && w < wave)) dest += s_cnt[w][c];
-            s_perm[dest] = (uint16_t)threadIdx.x;
-            __syncthreads();
-            i = base + s_perm[threadIdx.x];
-        }
+        const uint32_t i = base + threadIdx.x;
         bool alive = false, shadow = false, skipped = false, emitted = false;
         if (i < count) {
-            const uint32_t q = queue ? queue[i] : i + sp.id_base;            // where this ray's state is
-            const uint32_t bounce = i < boundary ? sp.bounce_a : sp.bounce_b;
+            const uint32_t q = queue ? queue[i] : i;                         // where this ray's state is
             const float2 h2 = ld_stream(&hits[i]);
             if (!(h2.x < 0.0f)) {                                            // pt.wgsl:646: miss adds zero
                 const float4 o4 = ld_stream(&P.O[q]), d4 = ld_stream(&P.D[q]);
@@ -347,7 +310,7 @@ __global__ __launch_bounds__(SBLOCK) PT_SHADE_ATTR void k_shade(DevScene sc, Dev
                 uint32_t rng = __float_as_uint(o4.w);
                 const v3 ro = xyz(o4), rd = xyz(d4);
                 v3 thr = mk3(1.0f, 1.0f, 1.0f);                                      // pt.wgsl:639; raygen stores no throughput
-                if (bounce != 0u) { const float2 c2 = ld_stream(&P.C[q]); thr = mk3(d4.w, c2.x, c2.y); }
+                if (sp.bounce != 0u) { const float2 c2 = ld_stream(&P.C[q]); thr = mk3(d4.w, c2.x, c2.y); }
                 const HitInfo hit = make_hitinfo(sc, ro, rd, h2.x, __float_as_uint(h2.y));
                 if (hit.emission.x > 0.0f || hit.emission.y > 0.0f || hit.emission.z > 0.0f) {   // pt.wgsl:652-658
                     float att = rcp1(1.0f + hit.t * hit.t);
@@ -395,20 +358,19 @@ __global__ __launch_bounds__(SBLOCK) PT_SHADE_ATTR void k_shade(DevScene sc, Dev
                         v3 nd = normalize3(dir);
                         thr = mul3(thr, vdiv3(mk3(ev.x, ev.y, ev.z), max1(ev.w, PT_EPS)));   // pt.wgsl:696
                         alive = true;
-                        if (bounce > 2u) {                                    // pt.wgsl:699-705
+                        if (sp.bounce > 2u) {                                 // pt.wgsl:699-705
                             float pr = max1(max1(thr.x, thr.y), thr.z);
                             if (rng_f(rng) > pr) alive = false;
                             else thr = vdiv3(thr, pr);
                         }
-                        alive = alive & (bounce + 1u < sp.max_bounces);       // pt.wgsl:642: the loop ends; compaction drops the path
-                        if (alive) {
+                        if (alive && sp.bounce + 1u < sp.max_bounces) {
                             st_stream(&P.O[q], make_float4(no.x, no.y, no.z, __uint_as_float(rng)));
                             st_stream(&P.D[q], make_float4(nd.x, nd.y, nd.z, thr.x));
                             st_stream(&P.C[q], make_float2(thr.y, thr.z));
                         }
                     }
                 }
-            } else if (bounce != 0u) {
+            } else if (sp.bounce != 0u) {
                 // pt.wgsl:646-648: a miss adds `throughput * vec3f(0.0)` — nothing while the throughput is finite (x + +-0 = x, and
                 // the radiance is never -0), NaN in every component whose throughput is infinite or NaN (degenerate materials
                 // only; the camera ray's throughput is 1). Such a path leaves a record like an emissive hit's.
@@ -429,13 +391,6 @@ __global__ __launch_bounds__(SBLOCK) PT_SHADE_ATTR void k_shade(DevScene sc, Dev
                 }
             }
         }
-        if (SORT) {                                   // back to slot order for the ballot words
-            s_flags[i - base] = (uint8_t)((alive ? 1u : 0u) | (shadow ? 2u : 0u) | (skipped ? 4u : 0u) | (emitted ? 8u : 0u));
-            __syncthreads();
-            const uint32_t f = s_flags[threadIdx.x];
-            alive = (f & 1u) != 0u; shadow = (f & 2u) != 0u; skipped = (f & 4u) != 0u; emitted = (f & 8u) != 0u;
-            i = base + threadIdx.x;
-        }
         const uint64_t am = __ballot(alive), sm = __ballot(shadow), zm = __ballot(skipped), em = __ballot(emitted);
         if ((threadIdx.x & 63u) == 0u && i < count) {
             alive_mask[i >> 6] = am;
@@ -443,7 +398,6 @@ __global__ __launch_bounds__(SBLOCK) PT_SHADE_ATTR void k_shade(DevScene sc, Dev
             n_skipped += (uint32_t)__popcll(zm);
             n_emitted += (uint32_t)__popcll(em);
         }
-        if (SORT) __syncthreads();                    // s_cnt / s_perm / s_flags are reused by the next round
     }
     if (n_skipped) atomicAdd(&sp.stats[1], (unsigned long long)n_skipped);
     if (n_emitted) atomicAdd(&sp.stats[3], (unsigned long long)n_emitted);
@@ -462,10 +416,8 @@ __global__ __launch_bounds__(SBLOCK) PT_SHADE_ATTR void k_shade(DevScene sc, Dev
 void PT_LAUNCH_SHADE(hipStream_t s, int blocks, const DevScene &sc, DevPaths p, const uint32_t *queue,
                      const uint32_t *count, const float2 *hits, DevShadow sh, uint64_t *alive_mask,
                      uint64_t *shadow_mask, ShadeParams sp) {
-    if (sp.sort && sc.tri_class)
-        hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(SBLOCK), 0, s, sc, p, queue, count, hits, sh, alive_mask, shadow_mask, sp);
-    else
-        hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(SBLOCK), 0, s, sc, p, queue, count, hits, sh, alive_mask, shadow_mask, sp);
+    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(SBLOCK), 0, s, sc, p, queue, count, hits, sh, alive_mask,
+                       shadow_mask, sp);
 }
 
 #ifndef PT_SHADE_FAST

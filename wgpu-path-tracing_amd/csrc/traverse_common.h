@@ -107,9 +107,9 @@ PT_DEV float2 pack_hit(const Hit &h) {
 
 // ---- ray sources / result sinks of the two kernels ---------------------------------
 struct ExtendIO {
-    const float4 *O, *D; const uint32_t *queue; float2 *hits; uint32_t id_base;
+    const float4 *O, *D; const uint32_t *queue; float2 *hits;
     PT_DEV bool fetch(uint32_t slot, v3 &o, v3 &d, float &tlim) const {
-        uint32_t p = queue ? queue[slot] : slot + id_base;
+        uint32_t p = queue ? queue[slot] : slot;
         float4 o4 = O[p], d4 = D[p];
         o = xyz(o4); d = xyz(d4); tlim = 0.0f;
         return true;

@@ -473,8 +473,8 @@ void launch_own(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevS
 }  // namespace
 
 void pt_launch_extend_own(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &sc, DevPaths p,
-                          const uint32_t *queue, const uint32_t *count, float2 *hits, uint32_t id_base) {
-    ExtendIO io{p.O, p.D, queue, hits, id_base};
+                          const uint32_t *queue, const uint32_t *count, float2 *hits) {
+    ExtendIO io{p.O, p.D, queue, hits};
     if (cfg.cull) launch_own<MODE_EXTEND, true>(s, blocks, cfg, sc, io, count);
     else launch_own<MODE_EXTEND, false>(s, blocks, cfg, sc, io, count);
 }

@@ -167,7 +167,6 @@ static void read_options(napi_env env, napi_value obj, ptmi_options *o) {
     o->tree_builder = get_u32_prop(env, obj, "treeBuilder", o->tree_builder);
     o->leaves = get_u32_prop(env, obj, "leaves", o->leaves);
     o->leaf_tris = get_u32_prop(env, obj, "leafTris", o->leaf_tris);
-    o->shade_sort = get_u32_prop(env, obj, "shadeSort", o->shade_sort);
 }
 
 static napi_value js_set_options(napi_env env, napi_callback_info info) {

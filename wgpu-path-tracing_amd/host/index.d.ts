@@ -35,8 +35,6 @@ export interface TraceOptions {
   leaves?: 0 | 1 | 2;
   /** leaves = 2: most triangles per own leaf (0 = library default) */
   leafTris?: number;
-  /** 0 (library default) / 1 off / 2 `shade` deals each workgroup's segments to its lanes by the kind of hit (same results) */
-  shadeSort?: 0 | 1 | 2;
 }
 export interface Stats {
   paths: number; segments: number; shadowRays: number; frames: number; dispatches: number;

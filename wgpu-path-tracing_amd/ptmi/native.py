@@ -46,7 +46,7 @@ class Options(ctypes.Structure):
                 ("tile_parts", ctypes.c_uint32), ("tile_part", ctypes.c_uint32), ("tile_strip", ctypes.c_uint32),
                 ("perf_mode", ctypes.c_uint32), ("reserved_a", ctypes.c_uint32), ("overlap", ctypes.c_uint32),
                 ("reserved_b", ctypes.c_uint32 * 4), ("tree_builder", ctypes.c_uint32),
-                ("leaves", ctypes.c_uint32), ("leaf_tris", ctypes.c_uint32), ("shade_sort", ctypes.c_uint32)]
+                ("leaves", ctypes.c_uint32), ("leaf_tris", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 1)]
 
 
 class Stats(ctypes.Structure):
@@ -62,10 +62,10 @@ class Stats(ctypes.Structure):
                 ("upload_ms", ctypes.c_double), ("upload_tree_ms", ctypes.c_double), ("upload_copy_ms", ctypes.c_double),
                 ("leaves_used", ctypes.c_uint32), ("leaf_tris_used", ctypes.c_uint32),
                 ("extend_variant", ctypes.c_uint32), ("shadow_variant", ctypes.c_uint32), ("verify_failed", ctypes.c_uint64),
-                ("shade_sort_used", ctypes.c_uint32), ("interleaved", ctypes.c_uint32)]
+                ("reserved_stats", ctypes.c_uint32 * 2)]
 
     def as_dict(self):
-        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("segments_by_bounce",)}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("segments_by_bounce", "reserved_stats")}
         d["segments_by_bounce"] = [int(v) for v in self.segments_by_bounce if v]
         return d
 
