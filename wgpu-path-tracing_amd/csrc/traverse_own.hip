@@ -133,7 +133,25 @@ template <int MODE, bool CULL, int STACK, bool SPILL, int REFILL, class Mem, cla
 PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint32_t count, uint32_t gw,
                            uint32_t total_waves, uint32_t *stk, int stride, uint32_t *spill = nullptr, uint32_t spill_lanes = 0) {
     constexpr bool ANY = MODE == MODE_SHADOW;
-    constexpr int NODE_KEEP = ANY ? 2 : 3;
+    // how long a stream keeps running after a vote (traverse_common.h has the meaning; the values here are measured on the own image:
+    // 7 - 8 box steps and 1.4 - 2 short leaves per ray instead of 5 and 3 longer ones)
+#ifndef PT_OWN_NODE_STEPS
+#define PT_OWN_NODE_STEPS PT_NODE_STEPS
+#endif
+#ifndef PT_OWN_LEAF_STEPS
+#define PT_OWN_LEAF_STEPS PT_LEAF_STEPS
+#endif
+#ifndef PT_OWN_LEAF_KEEP
+#define PT_OWN_LEAF_KEEP PT_LEAF_KEEP
+#endif
+#ifndef PT_OWN_NODE_KEEP_EXTEND
+#define PT_OWN_NODE_KEEP_EXTEND 3
+#endif
+#ifndef PT_OWN_NODE_KEEP_SHADOW
+#define PT_OWN_NODE_KEEP_SHADOW 2
+#endif
+    constexpr int NODE_KEEP = ANY ? PT_OWN_NODE_KEEP_SHADOW : PT_OWN_NODE_KEEP_EXTEND;
+    constexpr int NODE_STEPS = PT_OWN_NODE_STEPS, LEAF_STEPS = PT_OWN_LEAF_STEPS, LEAF_KEEP = PT_OWN_LEAF_KEEP;
     const uint32_t lane = threadIdx.x & 63u;
     gw = uniform(gw);
     const uint32_t ngroups = (count + 63u) >> 6;
