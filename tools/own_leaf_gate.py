@@ -126,49 +126,56 @@ def main():
         scene = scenes.grid_1m() if name == "grid_1m" else scenes.make(name)
         cam = layout.make_camera(a.width, a.height)
         t0 = time.time()
-        # rows spread over the picture, until the ray budget is met
-        want = int(a.rays)
-        recs, got, rows_done = [], 0, 0
-        step = max(1, a.height // 64)
-        for y in list(range(step // 2, a.height, step)) + list(range(0, a.height, step)):
-            if got >= want:
-                break
-            rec, n = tap_rays(oracle, scene, cam, a.frames, y, y + 1, 1 << 22)
-            recs.append(rec); got += len(rec); rows_done += 1
-        rec = np.ascontiguousarray(np.concatenate(recs))
-        n_shadow = int((rec[:, 6] != 0).sum())
-        print(f"== {name}: {len(scene.tris)} triangles, {len(rec)} rays of {rows_done} rows x {a.frames} frames at {a.width}x{a.height} "
-              f"({len(rec) - n_shadow} closest-hit, {n_shadow} shadow), tapped in {time.time() - t0:.1f} s", flush=True)
         variants = [("ref", 1, 0, 0)]
         for k in ([0] if a.quick else [int(x) for x in a.leaf_tris.split(",")]):
             variants += [(f"own{k or ''}", 2, k, 0), (f"own{k or ''}q", 2, k, 1)]
-        out = {}
-        base = None
+        runs = []                                   # (tag, image, quant, deferred, box cost, sums, differing rays)
         for tag, leaves, k, quant in variants:
             t1 = time.time()
             img = Image(scene, leaves, k)
             if quant and img.qn is None:
                 print(f"  {tag}: no quantised image for this scene"); continue
-            tb = time.time() - t1
+            img.build_ms = (time.time() - t1) * 1e3
             for deferred in ((0,) if a.quick else (0, 1)):
-                box = 65.0 if leaves == 1 else (66.0 if quant else 54.0)
-                sums, diff = run(L, img, rec, quant, 1, deferred, want_diff=16)
-                c, s_, ec, es = per_ray(sums, box)
-                if base is None:
-                    base = {}
-                base.setdefault(deferred, (ec, es)) if leaves == 1 else None
-                rc = ec / base[deferred][0] if deferred in base else float("nan")
-                rs = es / base[deferred][1] if deferred in base and base[deferred][1] else float("nan")
-                print(f"  {tag:6s} {'def' if deferred else 'imm'}  nodes {img.info.n_wnodes:7d} depth {img.info.depth:2d} | closest: steps {c[0]:6.2f} leaves {c[1]:5.2f} "
-                      f"tris {c[2]:6.2f} est {ec:7.0f} ({rc:5.2f}) | shadow: steps {s_[0]:6.2f} leaves {s_[1]:5.2f} tris {s_[2]:6.2f} est {es:7.0f} ({rs:5.2f}) | "
-                      f"differ {int(sums[8])} + {int(sums[9])}, slow {int(sums[10])}, retraced {int(sums[11])} | build {tb * 1e3:.0f} ms", flush=True)
-                out[f"{tag}_{'def' if deferred else 'imm'}"] = {
-                    "nodes": img.info.n_wnodes, "depth": img.info.depth, "closest": c, "shadow": s_, "est_closest": ec, "est_shadow": es,
-                    "ratio_closest": rc, "ratio_shadow": rs, "differ_closest": int(sums[8]), "differ_shadow": int(sums[9]),
-                    "slow": int(sums[10]), "retraced": int(sums[11]), "rays": len(rec)}
-                for i in diff[:4]:
-                    r = rec[int(i)]
-                    print(f"      differing ray {int(i)}: o {r[0:3]} d {r[3:6]} dist {r[6]} reference t {r[7]} tri {r[8:9].view(np.uint32)[0]}")
+                runs.append([tag, img, quant, deferred, 65.0 if leaves == 1 else (66.0 if quant else 54.0), np.zeros(12, np.uint64), []])
+        # rows spread over the picture, a chunk of rays at a time, until the ray budget is met
+        want, got, rows_done, n_shadow = int(a.rays), 0, 0, 0
+        step = max(1, a.height // 64)
+        rows = list(range(step // 2, a.height, step)) + [y for y in range(a.height) if (y - step // 2) % step]
+        frame0 = 0
+        while got < want:
+            recs, chunk = [], 0
+            while chunk < (1 << 23) and got + chunk < want:
+                if rows_done == len(rows):          # the whole picture is used up: go on with the next frames
+                    rows_done = 0; frame0 += a.frames
+                cam["frame_index"] = frame0
+                rec, n = tap_rays(oracle, scene, cam, a.frames, rows[rows_done], rows[rows_done] + 1, 1 << 22)
+                recs.append(rec); chunk += len(rec); rows_done += 1
+            rec = np.ascontiguousarray(np.concatenate(recs))
+            got += len(rec); n_shadow += int((rec[:, 6] != 0).sum())
+            for r in runs:
+                sums, diff = run(L, r[1], rec, r[2], 1, r[3], want_diff=16)
+                r[5] += sums
+                r[6] += [rec[int(i)].copy() for i in diff[:4]]
+            print(f"   ... {got} rays", flush=True)
+        print(f"== {name}: {len(scene.tris)} triangles, {got} rays of a {a.width}x{a.height} render, frames {a.frames} at a time "
+              f"({got - n_shadow} closest-hit, {n_shadow} shadow), {time.time() - t0:.1f} s", flush=True)
+        out, base = {}, {}
+        for tag, img, quant, deferred, box, sums, diffs in runs:
+            c, s_, ec, es = per_ray(sums, box)
+            if tag == "ref":
+                base[deferred] = (ec, es)
+            rc = ec / base[deferred][0] if deferred in base else float("nan")
+            rs = es / base[deferred][1] if deferred in base and base[deferred][1] else float("nan")
+            print(f"  {tag:6s} {'def' if deferred else 'imm'}  nodes {img.info.n_wnodes:7d} depth {img.info.depth:2d} | closest: steps {c[0]:6.2f} leaves {c[1]:5.2f} "
+                  f"tris {c[2]:6.2f} est {ec:7.0f} ({rc:5.2f}) | shadow: steps {s_[0]:6.2f} leaves {s_[1]:5.2f} tris {s_[2]:6.2f} est {es:7.0f} ({rs:5.2f}) | "
+                  f"differ {int(sums[8])} + {int(sums[9])}, slow {int(sums[10])}, retraced {int(sums[11])} | build {img.build_ms:.0f} ms", flush=True)
+            out[f"{tag}_{'def' if deferred else 'imm'}"] = {
+                "nodes": img.info.n_wnodes, "depth": img.info.depth, "closest": c, "shadow": s_, "est_closest": ec, "est_shadow": es,
+                "ratio_closest": rc, "ratio_shadow": rs, "differ_closest": int(sums[8]), "differ_shadow": int(sums[9]),
+                "slow": int(sums[10]), "retraced": int(sums[11]), "rays": got, "closest_rays": int(sums[6]), "shadow_rays": int(sums[7])}
+            for r in diffs[:4]:
+                print(f"      differing ray: o {r[0:3]} d {r[3:6]} dist {r[6]} reference t {r[7]} tri {r[8:9].view(np.uint32)[0]}")
         report[name] = out
     if a.json:
         with open(a.json, "w") as f:

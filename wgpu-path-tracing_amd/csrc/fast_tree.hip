@@ -500,7 +500,7 @@ bool pt_build_own_tree(const ptmi_triangle *tris, const std::vector<uint32_t> &w
     if (dbg) std::fprintf(stderr, "own tree: %u triangles -> %zu nodes, %u leaves, depth %u; hierarchy %.1f ms, collapse %.1f, emit + rotations %.1f, padding %.1f\n",
                           n, out.wnodes.size() / 4, out.n_leaves, out.depth, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
     out.pad = pad;
-    out.safe_origin = (float)std::min(16.0 * biggest, 3.0e38);
+    out.safe_origin = (float)std::min(8.0 * biggest, 3.0e38);      // the rounding of the fused tests stays below a quarter of the padding up to here
     return true;
 }
 
