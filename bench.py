@@ -57,7 +57,7 @@ def shadow_bytes_per_ray(l_bytes=12):
     per-path radiance at 16-byte stride (scenes walked from memory; ptmi_stats.radiance_stride_bytes)."""
     return 4 + SHADOW_RECORD_BYTES + 2 * l_bytes
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
-PROFILE_TAG = "r03"                     # profiles/<tag>_cfgN_*.json are the counter passes replayed in `roofline`
+PROFILE_TAG = "r04"                     # profiles/<tag>_cfgN_*.json are the counter passes replayed in `roofline`
 
 # kernel names in the counter files (tools/pmc_summary.py): traverse.hip's and traverse_own.hip's; a config runs one per kind
 EXTEND_KEYS = ("k_trace_lds/extend", "k_trace_global/extend", "k_own_lds/extend", "k_own_global/extend")

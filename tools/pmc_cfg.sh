@@ -8,7 +8,7 @@ for grp in "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SAL
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $out/g$i -- python3 bench.py --config $cfg --no-cpu-baseline "$@" > /dev/null 2> $out/g$i.err || echo "group $i failed: $grp"
+  rocprofv3 --pmc $grp --output-format csv -d $out/g$i -- python3 bench.py --config $cfg --no-cpu-baseline --no-leaves-compare "$@" > /dev/null 2> $out/g$i.err || echo "group $i failed: $grp"
 done
 python3 tools/pmc_summary.py --json ${PT_COMMIT:+--commit $PT_COMMIT} $(find $out -name "*counter_collection.csv") > $out/summary.json
 rm -rf $out/g[0-9]

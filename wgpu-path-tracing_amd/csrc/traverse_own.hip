@@ -38,6 +38,11 @@
 
 namespace {
 
+// refill when at most this many of the 64 lanes still hold a ray (scene in LDS; traverse_common.h has the value of the other kernels)
+#ifndef PT_OWN_REFILL_AT
+#define PT_OWN_REFILL_AT PT_REFILL_AT
+#endif
+
 typedef const __attribute__((address_space(1))) uint32_t *glb_u32p;
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) u4v *glb_u4p;
@@ -144,13 +149,17 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
 #ifndef PT_OWN_LEAF_KEEP
 #define PT_OWN_LEAF_KEEP PT_LEAF_KEEP
 #endif
+    // The box stream goes on while at least 1 / NODE_KEEP of the lanes that started it can: with the scene in LDS longer than over the
+    // reference's leaves (1/6 and 1/4 instead of 1/3 and 1/2: config 1 +1.5 ... +2 %, config 2 +2.3 %, tools/sessions/r04/s07.sh) — a ray is
+    // mostly box steps now; the kernels that walk memory keep 1/3 and 1/2 (config 3: 6 / 4 is -1.5 %).
 #ifndef PT_OWN_NODE_KEEP_EXTEND
-#define PT_OWN_NODE_KEEP_EXTEND 3
+#define PT_OWN_NODE_KEEP_EXTEND 6
 #endif
 #ifndef PT_OWN_NODE_KEEP_SHADOW
-#define PT_OWN_NODE_KEEP_SHADOW 2
+#define PT_OWN_NODE_KEEP_SHADOW 4
 #endif
-    constexpr int NODE_KEEP = ANY ? PT_OWN_NODE_KEEP_SHADOW : PT_OWN_NODE_KEEP_EXTEND;
+    constexpr bool FROM_MEMORY = REFILL == PT_REFILL_GLOBAL && PT_REFILL_GLOBAL != PT_OWN_REFILL_AT;
+    constexpr int NODE_KEEP = FROM_MEMORY ? (ANY ? 2 : 3) : (ANY ? PT_OWN_NODE_KEEP_SHADOW : PT_OWN_NODE_KEEP_EXTEND);
     constexpr int NODE_STEPS = PT_OWN_NODE_STEPS, LEAF_STEPS = PT_OWN_LEAF_STEPS, LEAF_KEEP = PT_OWN_LEAF_KEEP;
     const uint32_t lane = threadIdx.x & 63u;
     gw = uniform(gw);
@@ -362,10 +371,6 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
 
 // ------------------------------------------------------------------ kernels ----
 constexpr int GBLOCK = 256, LBLOCK = 1024;
-// refill when at most this many of the 64 lanes still hold a ray (scene in LDS; traverse_common.h has the value of the other kernels)
-#ifndef PT_OWN_REFILL_AT
-#define PT_OWN_REFILL_AT PT_REFILL_AT
-#endif
 
 #ifndef PT_OWN_LDS_WAVES
 #define PT_OWN_LDS_WAVES 0
