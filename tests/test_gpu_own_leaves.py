@@ -18,7 +18,8 @@ from test_gpu_parity import _test_rays, assert_same_floats, bits
 pytestmark = pytest.mark.gpu
 
 # PT_VARIANT_OWN_* x 10 + workgroups per CU (csrc/pt_device.h), as ptmi_stats.extend_variant / shadow_variant report them
-VARIANTS = {"lds": 41, "lds_nodes2": 52, "lds_nodes1": 51, "qlds": 61, "qlds_nodes2": 72, "qlds_nodes1": 71, "qglobal": 81, "global": 91}
+VARIANTS = {"lds": 41, "lds_nodes2": 52, "lds_nodes1": 51, "qlds": 61, "qlds_nodes2": 72, "qlds_nodes1": 71, "qglobal": 81, "global": 91,
+            "lds16_nodes2": 102}          # exact nodes with 16-bit references and stack entries (scenes up to 4 096 triangles)
 
 
 @pytest.fixture()
@@ -33,8 +34,9 @@ def own_ctx(gpu_ctx):
 
 
 def force(kind, code):
-    """PTMI_OWN_EXTEND / PTMI_OWN_SHADOW = variant + 10 for two workgroups per CU (csrc/ptmi_api.hip own_config)"""
-    os.environ["PTMI_OWN_EXTEND" if kind == "extend" else "PTMI_OWN_SHADOW"] = str(code // 10 + (10 if code % 10 == 2 else 0))
+    """PTMI_OWN_EXTEND / PTMI_OWN_SHADOW = variant + 10 for two workgroups per CU, 20 for the compact-reference variant
+    (csrc/ptmi_api.hip own_config)"""
+    os.environ["PTMI_OWN_EXTEND" if kind == "extend" else "PTMI_OWN_SHADOW"] = "20" if code == 102 else str(code // 10 + (10 if code % 10 == 2 else 0))
 
 
 def more_rays(sc, n, seed):
@@ -77,7 +79,7 @@ def test_every_memory_variant_returns_the_oracles_hits(own_ctx, oracle, scene_fa
     assert st.leaves_used == 2
     # the variants that fit this scene really ran (the others fell back to the library's choice)
     # (Cornell: 634 nodes — 40 KB exact, 20 KB quantised — and 48 KB of triangles beside 60 / 64 KB of stacks)
-    want = {"cornell": {41, 51, 61, 72, 71, 81, 91}, "feature_box": {81, 91}, "cornell_spheres": {71, 81, 91}, "grid_1m": {81, 91}}[name]
+    want = {"cornell": {41, 51, 61, 72, 71, 81, 91, 102}, "feature_box": {81, 91, 102}, "cornell_spheres": {71, 81, 91}, "grid_1m": {81, 91}}[name]
     assert want <= {u for u, _ in ran}, (name, sorted(ran))
     assert want <= {s for _, s in ran}, (name, sorted(ran))
 

@@ -55,6 +55,10 @@ struct DevScene {
     const float4 *tri_leafbox;  // per ORIGINAL triangle index: (min.xyz, 0), (max.xyz, 0) of the reference leaf that lists it
     float ref_root_min[3], ref_root_max[3];
     float safe_origin;          // |o|_inf up to which the boxes' padding covers the rounding of the fused slab test
+    // compact references (scenes of up to 4 096 triangles, NULL otherwise): copies of wnodes / ref_wnodes whose child references are 16 bits —
+    // an internal node's index, or 0x8000 | (count - 1) << 12 | first triangle — for the kernels with 16-bit stack entries
+    const float4 *wnodes16, *ref_wnodes16;
+    uint32_t root_ref16, ref_root_ref16;
     unsigned long long *verify_stat;    // += rays whose winner failed its reference leaf's box and were traced again
     const DevScene *self;       // this description in device memory (the own-leaf kernels read it from there, not from kernel arguments)
 };
@@ -113,7 +117,8 @@ struct ShadeParams {
 enum { PT_VARIANT_GLOBAL = 1, PT_VARIANT_LDS = 2, PT_VARIANT_LDS_NODES = 3,
        // own leaves (traverse_own.hip): exact / quantised nodes in LDS, with (…_LDS) or without (…_NODES) the triangle images, or from memory
        PT_VARIANT_OWN_LDS = 4, PT_VARIANT_OWN_LDS_NODES = 5, PT_VARIANT_OWN_QLDS = 6, PT_VARIANT_OWN_QLDS_NODES = 7,
-       PT_VARIANT_OWN_QGLOBAL = 8, PT_VARIANT_OWN_GLOBAL = 9 };
+       PT_VARIANT_OWN_QGLOBAL = 8, PT_VARIANT_OWN_GLOBAL = 9,
+       PT_VARIANT_OWN_LDS16_NODES = 10 };       // exact nodes with 16-bit references and 16-bit stack entries (scenes up to 4 096 triangles)
 
 struct TraverseConfig {
     int variant;            // PT_VARIANT_*

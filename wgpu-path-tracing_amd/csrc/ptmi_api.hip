@@ -55,7 +55,7 @@ struct ptmi_ctx {
     // scene (bindings 1, 2, 4, 5, 6)
     void *d_tris = nullptr, *d_mats = nullptr, *d_lights = nullptr, *d_atlas = nullptr;
     float4 *d_wnodes = nullptr, *d_tripos = nullptr, *d_fast_wnodes = nullptr;
-    float4 *d_own_tripos = nullptr, *d_leafbox = nullptr;
+    float4 *d_own_tripos = nullptr, *d_leafbox = nullptr, *d_wnodes16 = nullptr, *d_ref_wnodes16 = nullptr;
     DevScene *d_scene = nullptr;                       // sc in device memory (DevScene::self), rewritten whenever sc changes               // own leaves: leaf-ordered triangle images, per-triangle reference leaf boxes
     uint4 *d_qnodes = nullptr; uint32_t *d_leaf_stream = nullptr;        // quantised image of the rebuilt hierarchy (global variant)
     DevScene sc{};
@@ -234,7 +234,34 @@ struct Built {
     PtOwnTree own_tree;
     std::vector<uint4> own_qnodes;           // quantised nodes of own_tree (empty: a 16-bit grid does not resolve this scene)
     std::vector<float4> leafbox;             // 2 float4 per triangle (original index): its reference leaf's box
+    std::vector<float4> own_wnodes16, ref_wnodes16;   // the two hierarchies with 16-bit child references (empty: the scene is too large for them)
+    uint32_t own_root16 = PT_REF_NONE, ref_root16 = PT_REF_NONE;
 };
+
+// a copy of a wide-node image whose child references fit 16 bits: an internal node's index, or 0x8000 | (count - 1) << 12 | first
+// triangle. false: some reference does not fit (more than 32 767 nodes, a leaf beyond triangle 4 095 or of more than 8 triangles)
+bool compact_refs(const std::vector<float4> &w, uint32_t root, std::vector<float4> &out, uint32_t &root16) {
+    auto conv = [](uint32_t r, uint32_t &o) -> bool {
+        if (r & PT_REF_LEAF) {
+            const uint32_t first = r & PT_LEAF_OFF_MASK, cnt = ((r >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) + 1u;
+            if (first > 0xFFFu || cnt > 8u) return false;
+            o = 0x8000u | ((cnt - 1u) << 12) | first;
+        } else {
+            if (r > 0x7FFFu) return false;
+            o = r;
+        }
+        return true;
+    };
+    out = w;
+    if (root == PT_REF_NONE || !conv(root, root16)) return false;
+    for (size_t i = 0; i < w.size() / 4; i++) {
+        uint32_t l, r, l16, r16;
+        std::memcpy(&l, &w[i * 4 + 3].x, 4); std::memcpy(&r, &w[i * 4 + 3].y, 4);
+        if (!conv(l, l16) || !conv(r, r16)) return false;
+        std::memcpy(&out[i * 4 + 3].x, &l16, 4); std::memcpy(&out[i * 4 + 3].y, &r16, 4);
+    }
+    return true;
+}
 
 #ifndef PT_LEAVES_DEFAULT
 #define PT_LEAVES_DEFAULT 2            /* what ptmi_options.leaves = 0 means (measured: profiles/README.md) */
@@ -421,6 +448,7 @@ TraverseConfig own_config(const ptmi_ctx *c, bool closest_hit) {
         case PT_VARIANT_OWN_QLDS_NODES: return quant && (wgs == 2 ? two_ok && nq + two_b <= kLdsMax / 2 : nq + spill_b <= kLdsMax);
         case PT_VARIANT_OWN_QGLOBAL: return quant;
         case PT_VARIANT_OWN_GLOBAL: return true;
+        case PT_VARIANT_OWN_LDS16_NODES: return wgs == 2 && c->sc.wnodes16 != nullptr && two_ok && ne + two_b / 2 <= kLdsMax / 2;
         }
         return false;
     };
@@ -428,7 +456,7 @@ TraverseConfig own_config(const ptmi_ctx *c, bool closest_hit) {
         cfg.variant = variant; cfg.wgs_per_cu = wgs;
         const bool lds_full = variant == PT_VARIANT_OWN_LDS || variant == PT_VARIANT_OWN_QLDS;
         const bool global = variant == PT_VARIANT_OWN_QGLOBAL || variant == PT_VARIANT_OWN_GLOBAL;
-        cfg.stack_entries = lds_full ? full_stack : wgs == 2 ? 15 : 16;
+        cfg.stack_entries = lds_full ? full_stack : wgs == 2 ? 15 : 16;      // (16-bit entries in the compact-reference variant)
         cfg.wants_spill = (global || (!lds_full && wgs == 1)) ? 1 : 0;
         cfg.quantized = (variant == PT_VARIANT_OWN_QLDS || variant == PT_VARIANT_OWN_QLDS_NODES || variant == PT_VARIANT_OWN_QGLOBAL) ? 1 : 0;
     };
@@ -442,16 +470,17 @@ TraverseConfig own_config(const ptmi_ctx *c, bool closest_hit) {
         return cfg;
     }
     if (const char *e = std::getenv(closest_hit ? "PTMI_OWN_EXTEND" : "PTMI_OWN_SHADOW")) {
-        const int v = std::atoi(e) % 10, w = std::atoi(e) >= 10 ? 2 : 1;        // e.g. 7 = quantised nodes, one workgroup; 17 = two
+        const int raw = std::atoi(e);
+        const int v = raw == 20 ? (int)PT_VARIANT_OWN_LDS16_NODES : raw % 10, w = raw >= 10 ? 2 : 1;   // e.g. 7 = quantised nodes, one workgroup; 17 = two; 20 = compact references
         if (fits(v, w)) { take(v, w); return cfg; }
     }
     struct Pick { int variant, wgs; };
     // Both kernels are box-step heavy over own leaves (7 - 8 dependent node fetches per ray against 3 - 4 triangle tests) and gain from
     // the second workgroup per CU — 8 waves per SIMD to cover them — more than from resident triangles (config 1, same box: any-hit
     // kernel from two workgroups with quantised nodes 17.1 ms beside the main stream against 21.1 from the full image, +2 % overall)
-    static const Pick closest[] = {{PT_VARIANT_OWN_LDS_NODES, 2}, {PT_VARIANT_OWN_QLDS_NODES, 2}, {PT_VARIANT_OWN_LDS, 1}, {PT_VARIANT_OWN_QLDS, 1},
+    static const Pick closest[] = {{PT_VARIANT_OWN_LDS_NODES, 2}, {PT_VARIANT_OWN_LDS16_NODES, 2}, {PT_VARIANT_OWN_QLDS_NODES, 2}, {PT_VARIANT_OWN_LDS, 1}, {PT_VARIANT_OWN_QLDS, 1},
                                    {PT_VARIANT_OWN_QLDS_NODES, 1}, {PT_VARIANT_OWN_LDS_NODES, 1}};
-    static const Pick any[] = {{PT_VARIANT_OWN_LDS_NODES, 2}, {PT_VARIANT_OWN_QLDS_NODES, 2}, {PT_VARIANT_OWN_LDS, 1}, {PT_VARIANT_OWN_QLDS, 1},
+    static const Pick any[] = {{PT_VARIANT_OWN_LDS_NODES, 2}, {PT_VARIANT_OWN_LDS16_NODES, 2}, {PT_VARIANT_OWN_QLDS_NODES, 2}, {PT_VARIANT_OWN_LDS, 1}, {PT_VARIANT_OWN_QLDS, 1},
                                {PT_VARIANT_OWN_QLDS_NODES, 1}, {PT_VARIANT_OWN_LDS_NODES, 1}};
     if (!big) {
         if (closest_hit) { for (const Pick &p : closest) if (fits(p.variant, p.wgs)) { take(p.variant, p.wgs); return cfg; } }
@@ -624,7 +653,7 @@ int ptmi_destroy(ptmi_ctx *c) {
         if (ln.side) (void)hipStreamDestroy(ln.side);
     }
     dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_atlas); dfree(c->d_wnodes); dfree(c->d_tripos);
-    dfree(c->d_fast_wnodes); dfree(c->d_qnodes); dfree(c->d_leaf_stream); dfree(c->d_own_tripos); dfree(c->d_leafbox);
+    dfree(c->d_fast_wnodes); dfree(c->d_qnodes); dfree(c->d_leaf_stream); dfree(c->d_own_tripos); dfree(c->d_leafbox); dfree(c->d_wnodes16); dfree(c->d_ref_wnodes16);
     dfree(c->d_out_own); dfree(c->d_stats); dfree(c->d_scene); dfree(c->d_blit_f32); dfree(c->d_blit_u8);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -682,6 +711,8 @@ int pt_install_scene(ptmi_ctx *c, const PtPrepared *prep) {
     const auto t_copy = clk::now();
     void *n_tris = nullptr, *n_mats = nullptr, *n_lights = nullptr;
     float4 *n_wnodes = nullptr, *n_tripos = nullptr, *n_fast = nullptr, *n_own_tripos = nullptr, *n_leafbox = nullptr;
+    float4 *n_w16 = nullptr, *n_r16 = nullptr;
+    const bool has16 = b.own && !b.own_wnodes16.empty();
     uint4 *n_qnodes = nullptr; uint32_t *n_stream = nullptr;
     const bool own = b.own;
     const std::vector<uint4> &qn = own ? b.own_qnodes : b.qnodes;
@@ -702,16 +733,19 @@ int pt_install_scene(ptmi_ctx *c, const PtPrepared *prep) {
     if (e == hipSuccess && fast) e = up(reinterpret_cast<void **>(&n_fast), walk.data(), walk.size() * 16);
     if (e == hipSuccess && own) e = up(reinterpret_cast<void **>(&n_own_tripos), b.own_tree.tripos.data(), b.own_tree.tripos.size() * 16);
     if (e == hipSuccess && own) e = up(reinterpret_cast<void **>(&n_leafbox), b.leafbox.data(), b.leafbox.size() * 16);
+    if (e == hipSuccess && has16) e = up(reinterpret_cast<void **>(&n_w16), b.own_wnodes16.data(), b.own_wnodes16.size() * 16);
+    if (e == hipSuccess && has16) e = up(reinterpret_cast<void **>(&n_r16), b.ref_wnodes16.data(), b.ref_wnodes16.size() * 16);
     if (e == hipSuccess && quant) e = up(reinterpret_cast<void **>(&n_qnodes), qn.data(), qn.size() * 16);
     if (e == hipSuccess && quant && !own) e = up(reinterpret_cast<void **>(&n_stream), b.leaf_stream.data(), b.leaf_stream.size() * 4);
     if (e != hipSuccess) {
         dfree(n_tris); dfree(n_mats); dfree(n_lights); dfree(n_wnodes); dfree(n_tripos); dfree(n_fast); dfree(n_qnodes); dfree(n_stream);
-        dfree(n_own_tripos); dfree(n_leafbox);
+        dfree(n_own_tripos); dfree(n_leafbox); dfree(n_w16); dfree(n_r16);
         return fail(c, PTMI_E_HIP, "scene upload failed: %s (the previous scene, if any, is still in place)", hipGetErrorString(e));
     }
     HIP_TRY(c, sync_all(c));                  // nothing in flight reads the old buffers any more
     dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_wnodes); dfree(c->d_tripos); dfree(c->d_fast_wnodes);
-    dfree(c->d_qnodes); dfree(c->d_leaf_stream); dfree(c->d_own_tripos); dfree(c->d_leafbox);
+    dfree(c->d_qnodes); dfree(c->d_leaf_stream); dfree(c->d_own_tripos); dfree(c->d_leafbox); dfree(c->d_wnodes16); dfree(c->d_ref_wnodes16);
+    c->d_wnodes16 = n_w16; c->d_ref_wnodes16 = n_r16;
     c->d_qnodes = n_qnodes; c->d_leaf_stream = n_stream;
     c->d_tris = n_tris; c->d_mats = n_mats; c->d_lights = n_lights;
     c->d_wnodes = n_wnodes; c->d_tripos = n_tripos; c->d_fast_wnodes = n_fast;
@@ -737,6 +771,8 @@ int pt_install_scene(ptmi_ctx *c, const PtPrepared *prep) {
     s.own = own ? 1u : 0u;
     s.n_own_tris = own ? (uint32_t)(b.own_tree.tripos.size() / 3) : 0u;
     s.tri_leafbox = c->d_leafbox;
+    s.wnodes16 = c->d_wnodes16; s.ref_wnodes16 = c->d_ref_wnodes16;
+    s.root_ref16 = has16 ? b.own_root16 : PT_REF_NONE; s.ref_root_ref16 = has16 ? b.ref_root16 : PT_REF_NONE;
     s.safe_origin = own ? b.own_tree.safe_origin : 0.0f;
     s.verify_stat = c->d_stats + 4;
     s.self = c->d_scene;

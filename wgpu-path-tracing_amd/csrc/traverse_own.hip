@@ -134,9 +134,22 @@ struct OwnQuantMem {
 // REFILL or fewer lanes still hold one (traverse.hip explains the scheduling; this is the same loop over the own image).
 // `slow` lanes walk the tree exactly as uploaded (DevScene::ref_wnodes, ref_tripos, both from global memory) with the contract's slab
 // arithmetic — the reference's computation; a wave runs the copy of the streams that can do so only while it holds such a lane.
-template <int MODE, bool CULL, int STACK, bool SPILL, int REFILL, class Mem, class IO>
+// E = uint16_t: COMPACT REFERENCES (scenes of up to 4 096 triangles): the per-lane entries are 16 bits — an internal node's index, or 0x8000 |
+// (count - 1) << 12 | first triangle for a leaf — as the node images DevScene::wnodes16 / ref_wnodes16 carry them. Fifteen entries of a
+// 1024-thread workgroup are then 30 KB instead of 60, and a tree of up to 780 EXACT nodes (59 vector instructions a box step instead of
+// the quantised nodes' 66) runs two workgroups per CU.
+template <int MODE, bool CULL, int STACK, bool SPILL, int REFILL, class Mem, class IO, class E>
 PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint32_t count, uint32_t gw,
-                           uint32_t total_waves, uint32_t *stk, int stride, uint32_t *spill = nullptr, uint32_t spill_lanes = 0) {
+                           uint32_t total_waves, E *stk, int stride, uint32_t *spill = nullptr, uint32_t spill_lanes = 0) {
+    constexpr bool R16 = sizeof(E) == 2;
+    static_assert(!(R16 && SPILL), "the spill area holds 32-bit entries");
+    constexpr uint32_t LEAF_BIT = R16 ? 0x8000u : PT_REF_LEAF;
+    typedef __attribute__((address_space(3))) E *lds_ep;
+    auto room = [](lds_ep a, lds_ep b, int st) { return (int)((uint32_t)(uintptr_t)a - (uint32_t)(uintptr_t)b) >= st * (int)sizeof(E); };
+    auto open_leaf = [](uint32_t ref, uint32_t &first, uint32_t &cnt) {
+        if (R16) { first = ref & 0xFFFu; cnt = ((ref >> 12) & 7u) + 1u; }
+        else { first = ref & PT_LEAF_OFF_MASK; cnt = ((ref >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) + 1u; }
+    };
     constexpr bool ANY = MODE == MODE_SHADOW;
     // how long a stream keeps running after a vote (traverse_common.h has the meaning; the values here are measured on the own image:
     // 7 - 8 box steps and 1.4 - 2 short leaves per ray instead of 5 and 3 longer ones)
@@ -169,8 +182,8 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
     bool active = false, slow = false;
     bool fin = false, fin_occ = false;      // the ray has finished; its winner is verified and its result written at the next refill
     uint32_t slot = 0, cur = PT_REF_NONE;
-    const lds_u32p bot = (lds_u32p)stk, top = bot + (STACK - 1) * stride;
-    lds_u32p sp = bot, lp = top;
+    const lds_ep bot = (lds_ep)stk, top = bot + (STACK - 1) * stride;
+    lds_ep sp = bot, lp = top;
     uint32_t spn = 0;
     v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
     typename Mem::Pre pre = m.prep(o, mk3(0, 0, 1));
@@ -191,8 +204,8 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
         sp = bot; lp = top; spn = 0u; cur = PT_REF_NONE;
         limit = (ANY && CULL) ? cull_limit(tlim) : __builtin_inff();      // NaN for a directional light: never culls
         if (!hit) return false;
-        const uint32_t r = slow_ray ? sc.ref_root_ref : sc.root_ref;
-        if (r & PT_REF_LEAF) { *lp = r; lp -= stride; }                   // a one-leaf tree: file the root
+        const uint32_t r = R16 ? (slow_ray ? sc.ref_root_ref16 : sc.root_ref16) : (slow_ray ? sc.ref_root_ref : sc.root_ref);
+        if (r & LEAF_BIT) { *lp = (E)r; lp -= stride; }                   // a one-leaf tree: file the root
         else cur = r;
         return true;
     };
@@ -252,7 +265,7 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
         if (act == 0ull && next >= end) break;
         UTIL(0, 1); UTIL(1, popc(act));
 
-        const bool can_node = active & (cur != PT_REF_NONE) & ((int)room2(lp, sp, stride) | (int)(SPILL && (sp != bot) & room2(lp, bot, stride)));
+        const bool can_node = active & (cur != PT_REF_NONE) & ((int)room(lp, sp, stride) | (int)(SPILL && (sp != bot) & room(lp, bot, stride)));
         const bool can_tri = active & (lp != top);
         const uint64_t bn = ballot(can_node), bt = ballot(can_tri);
         const bool run_tri = popc(bt) > popc(bn);
@@ -269,8 +282,8 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
                 UTIL(6, 1); UTIL(7, popc(ballot(ct)));
                 if (ct) {
                     lp += stride;                                       // next filed leaf
-                    uint32_t first, cnt, cursor;
-                    open_plain(*lp, first, cnt, cursor);
+                    uint32_t first, cnt;
+                    open_leaf(*lp, first, cnt);
                     for (uint32_t k = 0; k < cnt; k++) {                // pt.wgsl:272-279
                         UTIL(8, uniform(lane) == lane ? 1 : 0); UTIL(9, 1);
                         float4 a, b, c;
@@ -307,8 +320,8 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
             for (int rep = 0; rep < NODE_STEPS; rep++) {
                 UTIL(4, 1); UTIL(5, popc(ballot(cn)));
                 if (cn) {
-                    if (SPILL && !room2(lp, sp, stride)) {              // rare: move the LDS node stack out
-                        for (lds_u32p q = bot; q != sp; q += stride) { spill[(size_t)spn * spill_lanes] = *q; spn++; }
+                    if (SPILL && !room(lp, sp, stride)) {               // rare: move the LDS node stack out
+                        for (lds_ep q = bot; q != sp; q += stride) { spill[(size_t)spn * spill_lanes] = *q; spn++; }
                         sp = bot;
                     }
                     float tl, tr;
@@ -316,7 +329,7 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
                     uint32_t lref, rref;
                     if (old) {
                         float4 a, b, c, r;
-                        load_node((glb_f4p)sc.ref_wnodes + 4u * (size_t)cur, a, b, c, r);
+                        load_node((glb_f4p)(R16 ? sc.ref_wnodes16 : sc.ref_wnodes) + 4u * (size_t)cur, a, b, c, r);
                         hl = slab(a.x, a.y, a.z, a.w, b.x, b.y, o, inv_old, tl);
                         hr = slab(b.z, b.w, c.x, c.y, c.z, c.w, o, inv_old, tr);
                         lref = __float_as_uint(r.x); rref = __float_as_uint(r.y);
@@ -324,27 +337,27 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
                         m.test(cur, pre, tl, tr, hl, hr, lref, rref);
                     }
                     if (CULL) { hl = hl & !(tl > limit); hr = hr & !(tr > limit); }
-                    const bool ll = (lref & PT_REF_LEAF) != 0u, rl = (rref & PT_REF_LEAF) != 0u;
-                    if (hl & ll) { *lp = lref; lp -= stride; }
-                    if (hr & rl) { *lp = rref; lp -= stride; }
+                    const bool ll = (lref & LEAF_BIT) != 0u, rl = (rref & LEAF_BIT) != 0u;
+                    if (hl & ll) { *lp = (E)lref; lp -= stride; }
+                    if (hr & rl) { *lp = (E)rref; lp -= stride; }
                     const bool il = hl & !ll, ir = hr & !rl;
                     const bool left_first = tl <= tr;
-                    if (il & ir) { *sp = left_first ? rref : lref; sp += stride; cur = left_first ? lref : rref; }
+                    if (il & ir) { *sp = (E)(left_first ? rref : lref); sp += stride; cur = left_first ? lref : rref; }
                     else if (il) cur = lref;
                     else if (ir) cur = rref;
                     else if (sp != bot) { sp -= stride; cur = *sp; }
                     else if (SPILL && spn != 0u) {                      // rare: take the last 8 spilled entries back
-                        const int fit = (int)((uint32_t)(uintptr_t)lp - (uint32_t)(uintptr_t)bot) / (stride * 4);   // free - 1
+                        const int fit = (int)((uint32_t)(uintptr_t)lp - (uint32_t)(uintptr_t)bot) / (stride * (int)sizeof(E));   // free - 1
                         uint32_t n = spn < 8u ? spn : 8u;
                         n = (int)n < fit ? n : (fit > 1 ? (uint32_t)fit : 1u);
                         spn -= n;
-                        for (uint32_t j = 0; j + 1u < n; j++) { *sp = spill[(size_t)(spn + j) * spill_lanes]; sp += stride; }
+                        for (uint32_t j = 0; j + 1u < n; j++) { *sp = (E)spill[(size_t)(spn + j) * spill_lanes]; sp += stride; }
                         cur = spill[(size_t)(spn + n - 1u) * spill_lanes];
                     }
                     else cur = PT_REF_NONE;
                 }
                 if (rep + 1 < NODE_STEPS) {
-                    cn = cn & (cur != PT_REF_NONE) & ((int)room2(lp, sp, stride) | (int)(SPILL && (sp != bot) & room2(lp, bot, stride)));
+                    cn = cn & (cur != PT_REF_NONE) & ((int)room(lp, sp, stride) | (int)(SPILL && (sp != bot) & room(lp, bot, stride)));
                     if (popc(ballot(cn)) * NODE_KEEP < popc(bn)) break;
                 }
             }
@@ -381,8 +394,8 @@ constexpr int GBLOCK = 256, LBLOCK = 1024;
 #define PT_OWN_LDS_ATTR
 #endif
 
-// LAYOUT: 0 exact nodes (64 B) in LDS, 1 quantised nodes (32 B) in LDS. TRIS: the triangle images in LDS too.
-// Dynamic LDS: [nodes][triangles][STACK x 1024 entries]
+// LAYOUT: 0 exact nodes (64 B) in LDS, 1 quantised nodes (32 B) in LDS, 2 exact nodes with compact references and 16-bit entries.
+// TRIS: the triangle images in LDS too. Dynamic LDS: [nodes][triangles][STACK x 1024 entries]
 // (STACK = 15 is the footprint of two workgroups per CU: 8 waves per SIMD, which the register allocator has to be told — at most 64
 // vector registers; left alone the max-ILP scheduler takes 72)
 template <int MODE, bool CULL, int STACK, int LAYOUT, bool TRIS, bool SPILL, class IO>
@@ -396,7 +409,7 @@ __global__ __launch_bounds__(LBLOCK) __attribute__((amdgpu_waves_per_eu(STACK ==
     const uint32_t count = *count_ptr;
     if (blockIdx.x * 64u >= count) return;      // wave 0 owns group blockIdx.x; if that is empty the whole group is idle
     const uint32_t nw = (LAYOUT == 1 ? 2u : 4u) * sc.n_wnodes, nt = TRIS ? 3u * sc.n_own_tris : 0u;
-    const float4 *src = LAYOUT == 1 ? reinterpret_cast<const float4 *>(sc.qnodes) : sc.wnodes;
+    const float4 *src = LAYOUT == 1 ? reinterpret_cast<const float4 *>(sc.qnodes) : LAYOUT == 2 ? sc.wnodes16 : sc.wnodes;
     for (uint32_t i = threadIdx.x; i < nw; i += LBLOCK) smem[i] = src[i];
     for (uint32_t i = threadIdx.x; i < nt; i += LBLOCK) smem[nw + i] = sc.tripos[i];
     __syncthreads();
@@ -404,7 +417,11 @@ __global__ __launch_bounds__(LBLOCK) __attribute__((amdgpu_waves_per_eu(STACK ==
     if (gw * 64u >= count) return;
     uint32_t *stk = reinterpret_cast<uint32_t *>(smem + nw + nt) + threadIdx.x;
     uint32_t *sp = SPILL ? spill + (size_t)blockIdx.x * LBLOCK + threadIdx.x : nullptr;
-    if constexpr (LAYOUT == 1) {
+    if constexpr (LAYOUT == 2) {
+        OwnLdsMem<TRIS> m{(lds_f4p)smem, (lds_f4p)(smem + nw), (glb_f4p)sc.tripos};
+        uint16_t *stk16 = reinterpret_cast<uint16_t *>(smem + nw + nt) + threadIdx.x;
+        trace_wave_own<MODE, CULL, STACK, false, PT_OWN_REFILL_AT>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk16, LBLOCK);
+    } else if constexpr (LAYOUT == 1) {
         OwnQuantMem<true, TRIS> m{(lds_u4p)smem, (glb_u4p)sc.qnodes, sc.n_wnodes, (lds_f4p)(smem + nw), (glb_f4p)sc.tripos,
                                   sc.q_origin[0], sc.q_origin[1], sc.q_origin[2], sc.q_scale[0], sc.q_scale[1], sc.q_scale[2]};
         trace_wave_own<MODE, CULL, STACK, SPILL, PT_OWN_REFILL_AT>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk, LBLOCK, sp, gridDim.x * LBLOCK);
@@ -468,7 +485,7 @@ template <int MODE, bool CULL, class IO>
 void launch_own(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevScene &hsc, const IO &io, const uint32_t *count) {
     const int cus = blocks / 8 > 0 ? blocks / 8 : 1;
     const DevScene *sc = hsc.self;              // the kernels read the description from device memory
-    const size_t node_bytes = (size_t)hsc.n_wnodes * (cfg.variant == PT_VARIANT_OWN_LDS || cfg.variant == PT_VARIANT_OWN_LDS_NODES ? 64 : 32);
+    const size_t node_bytes = (size_t)hsc.n_wnodes * (cfg.variant == PT_VARIANT_OWN_LDS || cfg.variant == PT_VARIANT_OWN_LDS_NODES || cfg.variant == PT_VARIANT_OWN_LDS16_NODES ? 64 : 32);
     const size_t tri_bytes = (size_t)hsc.n_own_tris * 48;
     const size_t stack_bytes = (size_t)cfg.stack_entries * LBLOCK * sizeof(uint32_t);
     switch (cfg.variant) {
@@ -487,6 +504,9 @@ void launch_own(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevS
     case PT_VARIANT_OWN_QLDS_NODES:             // quantised nodes resident, triangles through L1 / L2
         if (cfg.wgs_per_cu == 2) launch_own_lds<MODE, CULL, 15, 1, false, false>(s, 2 * cus, node_bytes + stack_bytes, sc, io, count, nullptr);
         else launch_own_lds<MODE, CULL, 16, 1, false, true>(s, cus, node_bytes + stack_bytes, sc, io, count, cfg.spill);
+        break;
+    case PT_VARIANT_OWN_LDS16_NODES:            // exact nodes with compact references, 16-bit entries: two workgroups per CU
+        launch_own_lds<MODE, CULL, 15, 2, false, false>(s, 2 * cus, node_bytes + stack_bytes / 2, sc, io, count, nullptr);
         break;
     case PT_VARIANT_OWN_QGLOBAL: launch_own_global<MODE, CULL, true>(s, cus, sc, io, count, cfg.spill); break;
     default: launch_own_global<MODE, CULL, false>(s, cus, sc, io, count, cfg.spill); break;
