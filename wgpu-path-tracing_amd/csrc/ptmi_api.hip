@@ -373,6 +373,10 @@ int build_image(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_
         // small scenes: at most 14 levels, so that a lane's whole node stack fits the 15 LDS entries of two workgroups per CU
         const uint32_t limit = which.size() <= 2048 ? 14u : 60u;
         b.own = pt_build_own_tree(tris, which, k_max, limit, b.own_tree);
+        if (b.own && nt <= 4096u) {                     // small scenes: both hierarchies once more with 16-bit child references
+            if (!compact_refs(b.own_tree.wnodes, b.own_tree.root_ref, b.own_wnodes16, b.own_root16) ||
+                !compact_refs(b.wnodes, b.root_ref, b.ref_wnodes16, b.ref_root16)) { b.own_wnodes16.clear(); b.ref_wnodes16.clear(); }
+        }
         if (b.own) {
             float qo[3], qs[3];
             if (pt_quantize_nodes(b.own_tree.wnodes, b.own_qnodes, qo, qs, PT_QCACHE_NODES, b.q_top))
