@@ -186,7 +186,9 @@ def valu_issue(config, is_profiled_workload, launches, gpu_ms):
             "source": {"file": os.path.relpath(path, ROOT), "counter": "SQ_ACTIVE_INST_VALU (quad-cycles per launch, all SIMDs)",
                        "code_commit": json.load(open(path)).get("_code_commit")},
             "note": "replayed from the committed counter pass of this command; extend, shade and shadow only (raygen, compaction and "
-                    "accumulate are streaming kernels); the clock under load is below the peak used here, so the true fraction is higher"}
+                    "accumulate are streaming kernels). busy_ms are issue times, not wall times: shadow runs on its own stream beside "
+                    "extend / shade, so the three kernels' event times add up to more than device_ms while their issue times cannot "
+                    "exceed it; the clock under load is below the peak used here, so the true fraction is higher"}
 
 
 def cpu_baseline(scene, cam_kw, width, height, bounces, mis, threads, target_s=12.0):

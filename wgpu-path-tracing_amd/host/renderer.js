@@ -139,13 +139,20 @@ Renderer.prototype.start = function () {
   var self = this;
   this.lastTime = Date.now();
   var animate = function () {
+    // Back-pressure without blocking the event loop (the reference's requestAnimationFrame loop never blocks: input events keep
+    // flowing): POLL how many dispatches are unfinished and come back on the next turn of the loop while more than one is — at
+    // most two in flight with the one a tick enqueues. A turn that only waits is not a tick: no update task runs.
+    if (self.sceneLoaded && self.api.throttle(self.ctx, 0xFFFFFFFF) > 1) {
+      self.throttledTurns = (self.throttledTurns || 0) + 1;
+      if (self.timer !== null) self.timer = setImmediate(animate);
+      return;
+    }
     var now = Date.now();
     var dt = (now - self.lastTime) / 1000;
     self.lastTime = now;
     for (var i = 0; i < self.onUpdateTasks.length; i++) self.onUpdateTasks[i](dt);      // may move the camera: framesPerTick = 1
     if (self.timer === null) return;        // an update task stopped the loop
     if (MAX_FRAMES === -1 || self.frameIndex < MAX_FRAMES) {
-      self.api.throttle(self.ctx, 1);       // back-pressure: at most one earlier dispatch unfinished, two in flight with this one
       var n = self.framesPerTick;
       if (MAX_FRAMES !== -1) n = Math.min(n, MAX_FRAMES - self.frameIndex);
       self.renderFrame(n);
