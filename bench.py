@@ -191,6 +191,31 @@ def valu_issue(config, is_profiled_workload, launches, gpu_ms):
                     "exceed it; the clock under load is below the peak used here, so the true fraction is higher"}
 
 
+def available_cores():
+    """The cores this process may actually use: the host's count, cut down to the scheduler affinity and to the cgroup's CPU quota (a
+    GPU box of the pool shows 256 host cores to a container that is allowed 16: 256 OpenMP threads on 16 cores' worth of time run at
+    15 Msamples/s where 16 threads reach 25). Returns (usable, host)."""
+    host = os.cpu_count() or 1
+    n = host
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(float(quota) / period + 0.5)))
+            break
+        except Exception:
+            continue
+    return max(1, n), host
+
+
 def cpu_baseline(scene, cam_kw, width, height, bounces, mis, threads, target_s=12.0):
     """Oracle on whole frames of the same camera: 1 calibration frame, then as many frames as
     fit in about target_s seconds (at most the 64 of the workload)."""
@@ -206,7 +231,7 @@ def cpu_baseline(scene, cam_kw, width, height, bounces, mis, threads, target_s=1
                        do_mis=mis, out=out, threads=threads)
     return {
         "value": round(st.segments / st.seconds / 1e6, 4), "unit": "Msamples/s", "cores": int(st.threads),
-        "cores_available": int(os.cpu_count() or 0),
+        "cores_available": available_cores()[0], "cores_host": available_cores()[1],
         "kind": "port",
         "sample": f"frames 1..{frames} of the full {width}x{height} frame: {st.paths} paths, {st.segments} segments "
                   f"in {st.seconds:.2f} s (oracle/pt_oracle.c contract build, OpenMP dynamic rows)",
@@ -615,7 +640,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             t_leg = time.perf_counter()
-            out["cpu_baseline"] = cpu_baseline(scene, cam_kw, W, H, cfg["bounces"], mis, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(scene, cam_kw, W, H, cfg["bounces"], mis, available_cores()[0])
             leg_seconds["cpu_baseline"] = round(time.perf_counter() - t_leg, 3)
         # where the wall time of this command went: the GPU is idle during the CPU-baseline leg (a sampled gpu_busy of 0 % has its reason here)
         out["leg_seconds"] = leg_seconds

@@ -4,7 +4,7 @@
 tag=${1:-r02}; cd "$(dirname "$0")/.."
 for f in gpurun_out/prof_$tag/${tag}_cfg*_{bench,bench_profiled,pmc,counters,per_bounce,lane_stats}.json gpurun_out/prof_$tag/${tag}_cfg1_bench_one_stream.json \
          gpurun_out/prof_$tag/${tag}_cfg*_kernel_stats.csv; do [ -s "$f" ] && cp "$f" profiles/; done
-[ -s gpurun_out/s12/upload.log ] && cp gpurun_out/s12/upload.log profiles/${tag}_upload_times.txt
+for f in gpurun_out/prof_$tag/${tag}_upload_times.txt gpurun_out/prof_$tag/${tag}_multi.json gpurun_out/prof_$tag/${tag}_multi_gather.json gpurun_out/prof_$tag/${tag}_cfg*_lane_stats_leaves*.json gpurun_out/prof_$tag/${tag}_cfg1_per_bounce_counters_leaves*.json; do [ -s "$f" ] && cp "$f" profiles/; done
 python3 - "$tag" <<'PY'
 import json, sys, glob
 tag = sys.argv[1]
