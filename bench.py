@@ -224,8 +224,15 @@ def cpu_baseline(scene, cam_kw, width, height, bounces, mis, threads, target_s=1
     import numpy as np
     orc = Oracle(strict=False)
     out = np.zeros((height, width, 4), np.float32)
-    _, st0 = orc.render(scene, layout.make_camera(width, height, **cam_kw), 1, max_bounces=bounces, do_mis=mis, out=out,
-                        threads=threads)
+    # one calibration frame on all usable cores — and, where a container is shown more cores than it is given time on (no quota to
+    # read), on 16 threads as well: the sample runs with whichever was faster (`cores` says which)
+    candidates = [threads] + ([16] if threads > 32 else [])
+    best = None
+    for th in candidates:
+        _, st = orc.render(scene, layout.make_camera(width, height, **cam_kw), 1, max_bounces=bounces, do_mis=mis, out=out, threads=th)
+        if best is None or st.seconds < best[1].seconds:
+            best = (th, st)
+    threads, st0 = best
     frames = int(max(1, min(63, target_s / max(st0.seconds, 1e-3))))
     _, st = orc.render(scene, layout.make_camera(width, height, frame_index=1, **cam_kw), frames, max_bounces=bounces,
                        do_mis=mis, out=out, threads=threads)

@@ -200,7 +200,13 @@ int ptmi_get_size(const ptmi_ctx *ctx, uint32_t *width, uint32_t *height);
  * /opt/rocm/include/rccl/rccl.h:745; single process, ncclCommInitAll over the listed devices) and unpacks them by row index into
  * device 0's output buffer, which then holds the frame exactly as one device would have rendered it — bit for bit.
  * librccl.so.1 is loaded when the first multi-device handle is created (not by single-device users of this library).
- * All calls are made from one host thread; work is enqueued asynchronously on one stream per device. */
+ * All calls are made from one host thread; work is enqueued asynchronously on one stream per device (ptmi_multi_dispatch itself
+ * enqueues every device from a thread of its own for the duration of the call: ~0.3 ms of host time per device and 64-frame batch).
+ * STATUS: what a one-GPU machine can check is checked — N = 1 through RCCL gives the un-sharded bits; N = 2 .. 8 contexts on one
+ * device with copies in place of the collective (PTMI_MULTI_LOOPBACK) assemble the single-device frame bit for bit. The real N > 1
+ * path (ncclCommInitAll over several devices, one grouped ncclGather with a NULL receive buffer on the non-roots, the unpack of slots
+ * 1 .. N-1) HAS NEVER RUN: every machine this library was built and tested on has one GPU. tests/test_gpu_multi.py holds the
+ * 2-device test; it skips itself below two GPUs. */
 typedef struct ptmi_multi ptmi_multi;
 enum {
     PTMI_MULTI_LOOPBACK = 1u    /* device-to-device copies in place of the collective: lets ONE device stand in for several (the same

@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 
 # PT_VARIANT_OWN_* x 10 + workgroups per CU (csrc/pt_device.h), as ptmi_stats.extend_variant / shadow_variant report them
 VARIANTS = {"lds": 41, "lds_nodes2": 52, "lds_nodes1": 51, "qlds": 61, "qlds_nodes2": 72, "qlds_nodes1": 71, "qglobal": 81, "global": 91,
-            "lds16_nodes2": 102}          # exact nodes with 16-bit references and stack entries (scenes up to 4 096 triangles)
+            "lds16_nodes2": 102,          # exact nodes with 16-bit references and stack entries (scenes up to 4 096 triangles)
+            "qlds16_nodes2": 112}         # quantised nodes with 16-bit references, 8 - 15 16-bit entries per lane, the node stack spills
 
 
 @pytest.fixture()
@@ -27,7 +28,7 @@ def own_ctx(gpu_ctx):
     before = gpu_ctx.options()
     gpu_ctx.set_options(leaves=2, leaf_tris=0, keep_reference_tree=0, traversal=native.TRAVERSAL_AUTO, cull=1)
     yield gpu_ctx
-    for k in ("PTMI_OWN_EXTEND", "PTMI_OWN_SHADOW"):
+    for k in ("PTMI_OWN_EXTEND", "PTMI_OWN_SHADOW", "PTMI_OWN_Q16_ENTRIES"):
         os.environ.pop(k, None)
     gpu_ctx.set_options(leaves=before.leaves, leaf_tris=before.leaf_tris, keep_reference_tree=0, traversal=native.TRAVERSAL_AUTO, cull=1,
                         max_bounces=8, do_mis=1, frames_per_batch=0, tile_y0=0, tile_y1=0)
@@ -36,7 +37,7 @@ def own_ctx(gpu_ctx):
 def force(kind, code):
     """PTMI_OWN_EXTEND / PTMI_OWN_SHADOW = variant + 10 for two workgroups per CU, 20 for the compact-reference variant
     (csrc/ptmi_api.hip own_config)"""
-    os.environ["PTMI_OWN_EXTEND" if kind == "extend" else "PTMI_OWN_SHADOW"] = "20" if code == 102 else str(code // 10 + (10 if code % 10 == 2 else 0))
+    os.environ["PTMI_OWN_EXTEND" if kind == "extend" else "PTMI_OWN_SHADOW"] = {102: "20", 112: "21"}.get(code) or str(code // 10 + (10 if code % 10 == 2 else 0))
 
 
 def more_rays(sc, n, seed):
@@ -79,7 +80,8 @@ def test_every_memory_variant_returns_the_oracles_hits(own_ctx, oracle, scene_fa
     assert st.leaves_used == 2
     # the variants that fit this scene really ran (the others fell back to the library's choice)
     # (Cornell: 634 nodes — 40 KB exact, 20 KB quantised — and 48 KB of triangles beside 60 / 64 KB of stacks)
-    want = {"cornell": {41, 51, 61, 72, 71, 81, 91, 102}, "feature_box": {81, 91, 102}, "cornell_spheres": {71, 81, 91}, "grid_1m": {81, 91}}[name]
+    # (cornell_spheres: 2 038 nodes — 64 KB quantised: 8 16-bit entries per lane beside them in half a CU's LDS, in a tree 19 levels deep)
+    want = {"cornell": {41, 51, 61, 72, 71, 81, 91, 102, 112}, "feature_box": {81, 91, 102, 112}, "cornell_spheres": {71, 81, 91, 112}, "grid_1m": {81, 91}}[name]
     assert want <= {u for u, _ in ran}, (name, sorted(ran))
     assert want <= {s for _, s in ran}, (name, sorted(ran))
 
@@ -108,6 +110,34 @@ def test_render_parity_with_own_leaves(own_ctx, oracle, scene_factory, case, lea
     assert (st.segments, st.shadow_rays, st.paths) == (ost.segments, ost.shadow_rays, ost.paths)
     assert_same_floats(got, ref, f"radiance {name} (own leaves of <= {leaf_tris or 'default'} triangles)")
     assert st.verify_failed <= 1e-4 * (st.segments + st.shadow_traced) + 2
+
+
+@pytest.mark.parametrize("name,W,H,frames", [("deep_chain", 64, 48, 2), ("cornell", 96, 64, 4), ("cornell_spheres", 96, 64, 3), ("feature_box", 72, 72, 4)])
+def test_spilling_short_stacks(own_ctx, oracle, scene_factory, name, W, H, frames):
+    """The two-workgroup kernels over quantised nodes with compact references keep 8 - 15 16-bit entries per lane (node stack from one
+    end, filed leaves from the other) and move the node stack to memory when the two meet: forced to 8 entries on trees 14 - 58 levels
+    deep, renders and ray tables must still be the oracle's."""
+    sc = scene_factory(name)
+    os.environ["PTMI_OWN_Q16_ENTRIES"] = "8"
+    force("extend", 112); force("shadow", 112)
+    own_ctx.upload_scene(sc)
+    o, d = more_rays(sc, 100_000, 5)
+    ot, otri, ou, ov, _ = oracle.intersect(sc, o, d)
+    gt, gtri, gu, gv = own_ctx.debug_intersect(o, d)
+    assert own_ctx.stats().extend_variant == 112
+    assert np.array_equal(gtri, otri); assert_same_floats(gt, ot, "t"); assert_same_floats(gu, ou, "u"); assert_same_floats(gv, ov, "v")
+    dist = (np.random.default_rng(2).random(len(o)) * 2.5).astype(np.float32)
+    assert np.array_equal(own_ctx.debug_occluded(o, d, dist), oracle.occluded(sc, o, d, dist))
+    cam = layout.make_camera(W, H, aperture=0.001, focus_distance=2.8)
+    ref, ost = oracle.render(sc, cam, frames, max_bounces=8, do_mis=1)
+    own_ctx.resize(W, H)
+    own_ctx.set_options(max_bounces=8, do_mis=1, tile_y0=0, tile_y1=0, frames_per_batch=0, cull=1)
+    own_ctx.reset_stats()
+    own_ctx.dispatch(cam, frames)
+    got, st = own_ctx.read_output(), own_ctx.stats()
+    assert (st.extend_variant, st.shadow_variant) == (112, 112)
+    assert (st.segments, st.shadow_rays) == (ost.segments, ost.shadow_rays)
+    assert_same_floats(got, ref, f"radiance {name}, 8-entry spilling stacks")
 
 
 def test_random_scene_fuzz_with_own_leaves(own_ctx, oracle):

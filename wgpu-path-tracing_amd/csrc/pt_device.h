@@ -59,6 +59,7 @@ struct DevScene {
     // an internal node's index, or 0x8000 | (count - 1) << 12 | first triangle — for the kernels with 16-bit stack entries
     const float4 *wnodes16, *ref_wnodes16;
     uint32_t root_ref16, ref_root_ref16;
+    const uint4 *qnodes16;      // qnodes with the same 16-bit references (NULL: none)
     unsigned long long *verify_stat;    // += rays whose winner failed its reference leaf's box and were traced again
     const DevScene *self;       // this description in device memory (the own-leaf kernels read it from there, not from kernel arguments)
 };
@@ -118,11 +119,13 @@ enum { PT_VARIANT_GLOBAL = 1, PT_VARIANT_LDS = 2, PT_VARIANT_LDS_NODES = 3,
        // own leaves (traverse_own.hip): exact / quantised nodes in LDS, with (…_LDS) or without (…_NODES) the triangle images, or from memory
        PT_VARIANT_OWN_LDS = 4, PT_VARIANT_OWN_LDS_NODES = 5, PT_VARIANT_OWN_QLDS = 6, PT_VARIANT_OWN_QLDS_NODES = 7,
        PT_VARIANT_OWN_QGLOBAL = 8, PT_VARIANT_OWN_GLOBAL = 9,
-       PT_VARIANT_OWN_LDS16_NODES = 10 };       // exact nodes with 16-bit references and 16-bit stack entries (scenes up to 4 096 triangles)
+       PT_VARIANT_OWN_LDS16_NODES = 10,         // exact nodes with 16-bit references and 16-bit stack entries (scenes up to 4 096 triangles)
+       PT_VARIANT_OWN_QLDS16_NODES = 11 };      // quantised nodes with 16-bit references: two workgroups per CU for trees of up to 2 046 nodes,
+                                                // 8 - 15 16-bit entries per lane (what the nodes leave of 80 KB), the node stack spills
 
 struct TraverseConfig {
     int variant;            // PT_VARIANT_*
-    int stack_entries;      // 15 (two workgroups per CU only), 16, 32 or 64
+    int stack_entries;      // 15 (two workgroups per CU only), 16, 32 or 64; PT_VARIANT_OWN_QLDS16_NODES: 8 ... 15
     int cull;               // 0/1
     size_t lds_scene_bytes; // LDS variant: bytes of wnodes + tripos
     int wgs_per_cu;         // node cache: 2 (small trees, whole stack in LDS) or 1 (mid-size trees, spilling stacks)

@@ -56,6 +56,7 @@ struct ptmi_ctx {
     void *d_tris = nullptr, *d_mats = nullptr, *d_lights = nullptr, *d_atlas = nullptr;
     float4 *d_wnodes = nullptr, *d_tripos = nullptr, *d_fast_wnodes = nullptr;
     float4 *d_own_tripos = nullptr, *d_leafbox = nullptr, *d_wnodes16 = nullptr, *d_ref_wnodes16 = nullptr;
+    uint4 *d_qnodes16 = nullptr;
     DevScene *d_scene = nullptr;                       // sc in device memory (DevScene::self), rewritten whenever sc changes               // own leaves: leaf-ordered triangle images, per-triangle reference leaf boxes
     uint4 *d_qnodes = nullptr; uint32_t *d_leaf_stream = nullptr;        // quantised image of the rebuilt hierarchy (global variant)
     DevScene sc{};
@@ -235,23 +236,25 @@ struct Built {
     std::vector<uint4> own_qnodes;           // quantised nodes of own_tree (empty: a 16-bit grid does not resolve this scene)
     std::vector<float4> leafbox;             // 2 float4 per triangle (original index): its reference leaf's box
     std::vector<float4> own_wnodes16, ref_wnodes16;   // the two hierarchies with 16-bit child references (empty: the scene is too large for them)
+    std::vector<uint4> own_qnodes16;         // own_qnodes with 16-bit child references (empty: no quantised image, or too large)
     uint32_t own_root16 = PT_REF_NONE, ref_root16 = PT_REF_NONE;
 };
 
 // a copy of a wide-node image whose child references fit 16 bits: an internal node's index, or 0x8000 | (count - 1) << 12 | first
 // triangle. false: some reference does not fit (more than 32 767 nodes, a leaf beyond triangle 4 095 or of more than 8 triangles)
+bool compact_ref(uint32_t r, uint32_t &o) {
+    if (r & PT_REF_LEAF) {
+        const uint32_t first = r & PT_LEAF_OFF_MASK, cnt = ((r >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) + 1u;
+        if (first > 0xFFFu || cnt > 8u) return false;
+        o = 0x8000u | ((cnt - 1u) << 12) | first;
+    } else {
+        if (r > 0x7FFFu) return false;
+        o = r;
+    }
+    return true;
+}
 bool compact_refs(const std::vector<float4> &w, uint32_t root, std::vector<float4> &out, uint32_t &root16) {
-    auto conv = [](uint32_t r, uint32_t &o) -> bool {
-        if (r & PT_REF_LEAF) {
-            const uint32_t first = r & PT_LEAF_OFF_MASK, cnt = ((r >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) + 1u;
-            if (first > 0xFFFu || cnt > 8u) return false;
-            o = 0x8000u | ((cnt - 1u) << 12) | first;
-        } else {
-            if (r > 0x7FFFu) return false;
-            o = r;
-        }
-        return true;
-    };
+    auto conv = compact_ref;
     out = w;
     if (root == PT_REF_NONE || !conv(root, root16)) return false;
     for (size_t i = 0; i < w.size() / 4; i++) {
@@ -382,6 +385,10 @@ int build_image(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_
             if (pt_quantize_nodes(b.own_tree.wnodes, b.own_qnodes, qo, qs, PT_QCACHE_NODES, b.q_top))
                 for (int k = 0; k < 3; k++) { b.q_origin[k] = qo[k]; b.q_scale[k] = qs[k]; }
             else b.own_qnodes.clear();
+            if (!b.own_qnodes.empty() && !b.own_wnodes16.empty()) {     // (the quantised nodes are renumbered: node 0 stays the root)
+                b.own_qnodes16 = b.own_qnodes;
+                for (uint4 &q : b.own_qnodes16) if (!compact_ref(q.w, q.w)) { b.own_qnodes16.clear(); break; }
+            }
         } else {
             b.leafbox.clear();
         }
@@ -444,6 +451,10 @@ TraverseConfig own_config(const ptmi_ctx *c, bool closest_hit) {
     const int full_stack = depth + 2 <= 16 ? 16 : depth + 2 <= 32 ? 32 : 0;
     const size_t full_b = (size_t)full_stack * 4096, two_b = (size_t)15 * 4096, spill_b = (size_t)16 * 4096;
     const bool two_ok = depth + 1 <= 15;                              // the whole node stack in 15 entries
+    // quantised nodes with compact references, two workgroups per CU: the 16-bit entries (2 KB each per workgroup) take what the nodes leave
+    int q16_entries = (c->sc.qnodes16 && nq + 64 < kLdsMax / 2) ? std::min<int>(15, (int)((kLdsMax / 2 - 64 - nq) / 2048)) : 0;
+    if (const char *e = std::getenv("PTMI_OWN_Q16_ENTRIES"))          // tests: a shorter stack than fits (more spills), never below 8 to pass `fits`
+        q16_entries = std::min(q16_entries, std::max(8, std::atoi(e)));
     auto fits = [&](int variant, int wgs) -> bool {
         switch (variant) {
         case PT_VARIANT_OWN_LDS: return full_stack && ne + tb + full_b <= kLdsMax;
@@ -453,6 +464,7 @@ TraverseConfig own_config(const ptmi_ctx *c, bool closest_hit) {
         case PT_VARIANT_OWN_QGLOBAL: return quant;
         case PT_VARIANT_OWN_GLOBAL: return true;
         case PT_VARIANT_OWN_LDS16_NODES: return wgs == 2 && c->sc.wnodes16 != nullptr && two_ok && ne + two_b / 2 <= kLdsMax / 2;
+        case PT_VARIANT_OWN_QLDS16_NODES: return wgs == 2 && quant && q16_entries >= 8;
         }
         return false;
     };
@@ -460,9 +472,10 @@ TraverseConfig own_config(const ptmi_ctx *c, bool closest_hit) {
         cfg.variant = variant; cfg.wgs_per_cu = wgs;
         const bool lds_full = variant == PT_VARIANT_OWN_LDS || variant == PT_VARIANT_OWN_QLDS;
         const bool global = variant == PT_VARIANT_OWN_QGLOBAL || variant == PT_VARIANT_OWN_GLOBAL;
-        cfg.stack_entries = lds_full ? full_stack : wgs == 2 ? 15 : 16;      // (16-bit entries in the compact-reference variant)
-        cfg.wants_spill = (global || (!lds_full && wgs == 1)) ? 1 : 0;
-        cfg.quantized = (variant == PT_VARIANT_OWN_QLDS || variant == PT_VARIANT_OWN_QLDS_NODES || variant == PT_VARIANT_OWN_QGLOBAL) ? 1 : 0;
+        const bool q16 = variant == PT_VARIANT_OWN_QLDS16_NODES;
+        cfg.stack_entries = q16 ? q16_entries : lds_full ? full_stack : wgs == 2 ? 15 : 16;      // (16-bit entries in the compact-reference variants)
+        cfg.wants_spill = (global || q16 || (!lds_full && wgs == 1)) ? 1 : 0;
+        cfg.quantized = (variant == PT_VARIANT_OWN_QLDS || variant == PT_VARIANT_OWN_QLDS_NODES || variant == PT_VARIANT_OWN_QGLOBAL || q16) ? 1 : 0;
     };
     const bool big = c->lds_scene_bytes > ((size_t)4 << 20);         // beyond an XCD's L2: the quantised nodes pay (traverse_config below)
     if (c->opt.traversal == PTMI_TRAVERSAL_GLOBAL) { take(quant ? PT_VARIANT_OWN_QGLOBAL : PT_VARIANT_OWN_GLOBAL, 1); return cfg; }
@@ -475,17 +488,18 @@ TraverseConfig own_config(const ptmi_ctx *c, bool closest_hit) {
     }
     if (const char *e = std::getenv(closest_hit ? "PTMI_OWN_EXTEND" : "PTMI_OWN_SHADOW")) {
         const int raw = std::atoi(e);
-        const int v = raw == 20 ? (int)PT_VARIANT_OWN_LDS16_NODES : raw % 10, w = raw >= 10 ? 2 : 1;   // e.g. 7 = quantised nodes, one workgroup; 17 = two; 20 = compact references
+        // e.g. 7 = quantised nodes, one workgroup; 17 = two; 20 = exact nodes with compact references; 21 = quantised nodes with compact references
+        const int v = raw == 20 ? (int)PT_VARIANT_OWN_LDS16_NODES : raw == 21 ? (int)PT_VARIANT_OWN_QLDS16_NODES : raw % 10, w = raw >= 10 ? 2 : 1;
         if (fits(v, w)) { take(v, w); return cfg; }
     }
     struct Pick { int variant, wgs; };
     // Both kernels are box-step heavy over own leaves (7 - 8 dependent node fetches per ray against 3 - 4 triangle tests) and gain from
     // the second workgroup per CU — 8 waves per SIMD to cover them — more than from resident triangles (config 1, same box: any-hit
     // kernel from two workgroups with quantised nodes 17.1 ms beside the main stream against 21.1 from the full image, +2 % overall)
-    static const Pick closest[] = {{PT_VARIANT_OWN_LDS_NODES, 2}, {PT_VARIANT_OWN_LDS16_NODES, 2}, {PT_VARIANT_OWN_QLDS_NODES, 2}, {PT_VARIANT_OWN_LDS, 1}, {PT_VARIANT_OWN_QLDS, 1},
-                                   {PT_VARIANT_OWN_QLDS_NODES, 1}, {PT_VARIANT_OWN_LDS_NODES, 1}};
-    static const Pick any[] = {{PT_VARIANT_OWN_LDS_NODES, 2}, {PT_VARIANT_OWN_LDS16_NODES, 2}, {PT_VARIANT_OWN_QLDS_NODES, 2}, {PT_VARIANT_OWN_LDS, 1}, {PT_VARIANT_OWN_QLDS, 1},
-                               {PT_VARIANT_OWN_QLDS_NODES, 1}, {PT_VARIANT_OWN_LDS_NODES, 1}};
+    static const Pick closest[] = {{PT_VARIANT_OWN_LDS_NODES, 2}, {PT_VARIANT_OWN_LDS16_NODES, 2}, {PT_VARIANT_OWN_QLDS_NODES, 2}, {PT_VARIANT_OWN_QLDS16_NODES, 2},
+                                   {PT_VARIANT_OWN_LDS, 1}, {PT_VARIANT_OWN_QLDS, 1}, {PT_VARIANT_OWN_QLDS_NODES, 1}, {PT_VARIANT_OWN_LDS_NODES, 1}};
+    static const Pick any[] = {{PT_VARIANT_OWN_LDS_NODES, 2}, {PT_VARIANT_OWN_LDS16_NODES, 2}, {PT_VARIANT_OWN_QLDS_NODES, 2}, {PT_VARIANT_OWN_QLDS16_NODES, 2},
+                               {PT_VARIANT_OWN_LDS, 1}, {PT_VARIANT_OWN_QLDS, 1}, {PT_VARIANT_OWN_QLDS_NODES, 1}, {PT_VARIANT_OWN_LDS_NODES, 1}};
     if (!big) {
         if (closest_hit) { for (const Pick &p : closest) if (fits(p.variant, p.wgs)) { take(p.variant, p.wgs); return cfg; } }
         else for (const Pick &p : any) if (fits(p.variant, p.wgs)) { take(p.variant, p.wgs); return cfg; }
@@ -658,6 +672,7 @@ int ptmi_destroy(ptmi_ctx *c) {
     }
     dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_atlas); dfree(c->d_wnodes); dfree(c->d_tripos);
     dfree(c->d_fast_wnodes); dfree(c->d_qnodes); dfree(c->d_leaf_stream); dfree(c->d_own_tripos); dfree(c->d_leafbox); dfree(c->d_wnodes16); dfree(c->d_ref_wnodes16);
+    dfree(c->d_qnodes16);
     dfree(c->d_out_own); dfree(c->d_stats); dfree(c->d_scene); dfree(c->d_blit_f32); dfree(c->d_blit_u8);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -717,8 +732,9 @@ int pt_install_scene(ptmi_ctx *c, const PtPrepared *prep) {
     float4 *n_wnodes = nullptr, *n_tripos = nullptr, *n_fast = nullptr, *n_own_tripos = nullptr, *n_leafbox = nullptr;
     float4 *n_w16 = nullptr, *n_r16 = nullptr;
     const bool has16 = b.own && !b.own_wnodes16.empty();
-    uint4 *n_qnodes = nullptr; uint32_t *n_stream = nullptr;
+    uint4 *n_qnodes = nullptr, *n_q16 = nullptr; uint32_t *n_stream = nullptr;
     const bool own = b.own;
+    const bool hasq16 = has16 && !b.own_qnodes16.empty();
     const std::vector<uint4> &qn = own ? b.own_qnodes : b.qnodes;
     const bool quant = !qn.empty();
     auto up = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
@@ -740,16 +756,18 @@ int pt_install_scene(ptmi_ctx *c, const PtPrepared *prep) {
     if (e == hipSuccess && has16) e = up(reinterpret_cast<void **>(&n_w16), b.own_wnodes16.data(), b.own_wnodes16.size() * 16);
     if (e == hipSuccess && has16) e = up(reinterpret_cast<void **>(&n_r16), b.ref_wnodes16.data(), b.ref_wnodes16.size() * 16);
     if (e == hipSuccess && quant) e = up(reinterpret_cast<void **>(&n_qnodes), qn.data(), qn.size() * 16);
+    if (e == hipSuccess && hasq16) e = up(reinterpret_cast<void **>(&n_q16), b.own_qnodes16.data(), b.own_qnodes16.size() * 16);
     if (e == hipSuccess && quant && !own) e = up(reinterpret_cast<void **>(&n_stream), b.leaf_stream.data(), b.leaf_stream.size() * 4);
     if (e != hipSuccess) {
         dfree(n_tris); dfree(n_mats); dfree(n_lights); dfree(n_wnodes); dfree(n_tripos); dfree(n_fast); dfree(n_qnodes); dfree(n_stream);
-        dfree(n_own_tripos); dfree(n_leafbox); dfree(n_w16); dfree(n_r16);
+        dfree(n_own_tripos); dfree(n_leafbox); dfree(n_w16); dfree(n_r16); dfree(n_q16);
         return fail(c, PTMI_E_HIP, "scene upload failed: %s (the previous scene, if any, is still in place)", hipGetErrorString(e));
     }
     HIP_TRY(c, sync_all(c));                  // nothing in flight reads the old buffers any more
     dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_wnodes); dfree(c->d_tripos); dfree(c->d_fast_wnodes);
     dfree(c->d_qnodes); dfree(c->d_leaf_stream); dfree(c->d_own_tripos); dfree(c->d_leafbox); dfree(c->d_wnodes16); dfree(c->d_ref_wnodes16);
     c->d_wnodes16 = n_w16; c->d_ref_wnodes16 = n_r16;
+    dfree(c->d_qnodes16); c->d_qnodes16 = n_q16;
     c->d_qnodes = n_qnodes; c->d_leaf_stream = n_stream;
     c->d_tris = n_tris; c->d_mats = n_mats; c->d_lights = n_lights;
     c->d_wnodes = n_wnodes; c->d_tripos = n_tripos; c->d_fast_wnodes = n_fast;
@@ -775,7 +793,7 @@ int pt_install_scene(ptmi_ctx *c, const PtPrepared *prep) {
     s.own = own ? 1u : 0u;
     s.n_own_tris = own ? (uint32_t)(b.own_tree.tripos.size() / 3) : 0u;
     s.tri_leafbox = c->d_leafbox;
-    s.wnodes16 = c->d_wnodes16; s.ref_wnodes16 = c->d_ref_wnodes16;
+    s.wnodes16 = c->d_wnodes16; s.ref_wnodes16 = c->d_ref_wnodes16; s.qnodes16 = c->d_qnodes16;
     s.root_ref16 = has16 ? b.own_root16 : PT_REF_NONE; s.ref_root_ref16 = has16 ? b.ref_root16 : PT_REF_NONE;
     s.safe_origin = own ? b.own_tree.safe_origin : 0.0f;
     s.verify_stat = c->d_stats + 4;

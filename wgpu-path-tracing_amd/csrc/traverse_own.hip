@@ -138,11 +138,12 @@ struct OwnQuantMem {
 // (count - 1) << 12 | first triangle for a leaf — as the node images DevScene::wnodes16 / ref_wnodes16 carry them. Fifteen entries of a
 // 1024-thread workgroup are then 30 KB instead of 60, and a tree of up to 780 EXACT nodes (59 vector instructions a box step instead of
 // the quantised nodes' 66) runs two workgroups per CU.
+// STACK = 0: `nstack` entries per lane, known at the launch only (the spill area holds 32-bit words: a 16-bit entry is widened there).
 template <int MODE, bool CULL, int STACK, bool SPILL, int REFILL, class Mem, class IO, class E>
 PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint32_t count, uint32_t gw,
-                           uint32_t total_waves, E *stk, int stride, uint32_t *spill = nullptr, uint32_t spill_lanes = 0) {
+                           uint32_t total_waves, E *stk, int stride, uint32_t *spill = nullptr, uint32_t spill_lanes = 0, int nstack = 0) {
     constexpr bool R16 = sizeof(E) == 2;
-    static_assert(!(R16 && SPILL), "the spill area holds 32-bit entries");
+    static_assert(STACK != 0 || SPILL, "a stack sized at the launch may be shorter than the tree is deep");
     constexpr uint32_t LEAF_BIT = R16 ? 0x8000u : PT_REF_LEAF;
     typedef __attribute__((address_space(3))) E *lds_ep;
     auto room = [](lds_ep a, lds_ep b, int st) { return (int)((uint32_t)(uintptr_t)a - (uint32_t)(uintptr_t)b) >= st * (int)sizeof(E); };
@@ -182,7 +183,7 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
     bool active = false, slow = false;
     bool fin = false, fin_occ = false;      // the ray has finished; its winner is verified and its result written at the next refill
     uint32_t slot = 0, cur = PT_REF_NONE;
-    const lds_ep bot = (lds_ep)stk, top = bot + (STACK - 1) * stride;
+    const lds_ep bot = (lds_ep)stk, top = bot + ((STACK ? STACK : nstack) - 1) * stride;
     lds_ep sp = bot, lp = top;
     uint32_t spn = 0;
     v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
@@ -394,13 +395,14 @@ constexpr int GBLOCK = 256, LBLOCK = 1024;
 #define PT_OWN_LDS_ATTR
 #endif
 
-// LAYOUT: 0 exact nodes (64 B) in LDS, 1 quantised nodes (32 B) in LDS, 2 exact nodes with compact references and 16-bit entries.
+// LAYOUT: 0 exact nodes (64 B) in LDS, 1 quantised nodes (32 B) in LDS, 2 exact nodes with compact references and 16-bit entries,
+// 3 quantised nodes with compact references and `nstack` 16-bit entries (STACK = 0, SPILL).
 // TRIS: the triangle images in LDS too. Dynamic LDS: [nodes][triangles][STACK x 1024 entries]
 // (STACK = 15 is the footprint of two workgroups per CU: 8 waves per SIMD, which the register allocator has to be told — at most 64
 // vector registers; left alone the max-ILP scheduler takes 72)
 template <int MODE, bool CULL, int STACK, int LAYOUT, bool TRIS, bool SPILL, class IO>
-__global__ __launch_bounds__(LBLOCK) __attribute__((amdgpu_waves_per_eu(STACK == 15 ? 8 : 4))) PT_OWN_LDS_ATTR void k_own_lds(const DevScene *__restrict__ scp, IO io, const uint32_t *__restrict__ count_ptr,
-                                                                    uint32_t *__restrict__ spill) {
+__global__ __launch_bounds__(LBLOCK) __attribute__((amdgpu_waves_per_eu((STACK == 15 || LAYOUT == 3) ? 8 : 4))) PT_OWN_LDS_ATTR void k_own_lds(const DevScene *__restrict__ scp, IO io, const uint32_t *__restrict__ count_ptr,
+                                                                    uint32_t *__restrict__ spill, int nstack) {
     // The scene description is read from memory where it is needed (the root boxes and limits at a refill, the uploaded tree by slow
     // rays, the leaf-box table at a verification) instead of living in scalar registers for the whole kernel: passed by value the
     // kernel took 104 of them, and two 1024-thread workgroups share a CU only up to 80 (traverse.hip: ShadowIO).
@@ -408,8 +410,9 @@ __global__ __launch_bounds__(LBLOCK) __attribute__((amdgpu_waves_per_eu(STACK ==
     extern __shared__ float4 smem[];
     const uint32_t count = *count_ptr;
     if (blockIdx.x * 64u >= count) return;      // wave 0 owns group blockIdx.x; if that is empty the whole group is idle
-    const uint32_t nw = (LAYOUT == 1 ? 2u : 4u) * sc.n_wnodes, nt = TRIS ? 3u * sc.n_own_tris : 0u;
-    const float4 *src = LAYOUT == 1 ? reinterpret_cast<const float4 *>(sc.qnodes) : LAYOUT == 2 ? sc.wnodes16 : sc.wnodes;
+    const uint32_t nw = ((LAYOUT == 1 || LAYOUT == 3) ? 2u : 4u) * sc.n_wnodes, nt = TRIS ? 3u * sc.n_own_tris : 0u;
+    const float4 *src = LAYOUT == 1 ? reinterpret_cast<const float4 *>(sc.qnodes) : LAYOUT == 3 ? reinterpret_cast<const float4 *>(sc.qnodes16)
+                      : LAYOUT == 2 ? sc.wnodes16 : sc.wnodes;
     for (uint32_t i = threadIdx.x; i < nw; i += LBLOCK) smem[i] = src[i];
     for (uint32_t i = threadIdx.x; i < nt; i += LBLOCK) smem[nw + i] = sc.tripos[i];
     __syncthreads();
@@ -421,6 +424,11 @@ __global__ __launch_bounds__(LBLOCK) __attribute__((amdgpu_waves_per_eu(STACK ==
         OwnLdsMem<TRIS> m{(lds_f4p)smem, (lds_f4p)(smem + nw), (glb_f4p)sc.tripos};
         uint16_t *stk16 = reinterpret_cast<uint16_t *>(smem + nw + nt) + threadIdx.x;
         trace_wave_own<MODE, CULL, STACK, false, PT_OWN_REFILL_AT>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk16, LBLOCK);
+    } else if constexpr (LAYOUT == 3) {
+        OwnQuantMem<true, false> m{(lds_u4p)smem, (glb_u4p)sc.qnodes16, sc.n_wnodes, (lds_f4p)nullptr, (glb_f4p)sc.tripos,
+                                   sc.q_origin[0], sc.q_origin[1], sc.q_origin[2], sc.q_scale[0], sc.q_scale[1], sc.q_scale[2]};
+        uint16_t *stk16 = reinterpret_cast<uint16_t *>(smem + nw + nt) + threadIdx.x;
+        trace_wave_own<MODE, CULL, 0, true, PT_OWN_REFILL_AT>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk16, LBLOCK, sp, gridDim.x * LBLOCK, nstack);
     } else if constexpr (LAYOUT == 1) {
         OwnQuantMem<true, TRIS> m{(lds_u4p)smem, (glb_u4p)sc.qnodes, sc.n_wnodes, (lds_f4p)(smem + nw), (glb_f4p)sc.tripos,
                                   sc.q_origin[0], sc.q_origin[1], sc.q_origin[2], sc.q_scale[0], sc.q_scale[1], sc.q_scale[2]};
@@ -432,7 +440,7 @@ __global__ __launch_bounds__(LBLOCK) __attribute__((amdgpu_waves_per_eu(STACK ==
 }
 
 template <int MODE, bool CULL, int STACK, int LAYOUT, bool TRIS, bool SPILL, class IO>
-void launch_own_lds(hipStream_t s, int wgs, size_t bytes, const DevScene *sc, const IO &io, const uint32_t *count, uint32_t *spill) {
+void launch_own_lds(hipStream_t s, int wgs, size_t bytes, const DevScene *sc, const IO &io, const uint32_t *count, uint32_t *spill, int nstack = 0) {
     static std::atomic<uint64_t> raised{0};      // the default dynamic-LDS cap is 64 KB; raise it once per instantiation and device
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -442,7 +450,7 @@ void launch_own_lds(hipStream_t s, int wgs, size_t bytes, const DevScene *sc, co
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         raised.fetch_or(bit, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((k_own_lds<MODE, CULL, STACK, LAYOUT, TRIS, SPILL, IO>), dim3(wgs), dim3(LBLOCK), bytes, s, sc, io, count, spill);
+    hipLaunchKernelGGL((k_own_lds<MODE, CULL, STACK, LAYOUT, TRIS, SPILL, IO>), dim3(wgs), dim3(LBLOCK), bytes, s, sc, io, count, spill, nstack);
 }
 
 // from global memory: 256-thread workgroups, 16 LDS entries per lane + the spill area; QUANT: quantised nodes, the top of the tree in LDS
@@ -507,6 +515,9 @@ void launch_own(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevS
         break;
     case PT_VARIANT_OWN_LDS16_NODES:            // exact nodes with compact references, 16-bit entries: two workgroups per CU
         launch_own_lds<MODE, CULL, 15, 2, false, false>(s, 2 * cus, node_bytes + stack_bytes / 2, sc, io, count, nullptr);
+        break;
+    case PT_VARIANT_OWN_QLDS16_NODES:           // quantised nodes with compact references: two workgroups per CU, stack_entries 16-bit entries, spills
+        launch_own_lds<MODE, CULL, 0, 3, false, true>(s, 2 * cus, node_bytes + (size_t)cfg.stack_entries * LBLOCK * sizeof(uint16_t), sc, io, count, cfg.spill, cfg.stack_entries);
         break;
     case PT_VARIANT_OWN_QGLOBAL: launch_own_global<MODE, CULL, true>(s, cus, sc, io, count, cfg.spill); break;
     default: launch_own_global<MODE, CULL, false>(s, cus, sc, io, count, cfg.spill); break;

@@ -43,7 +43,12 @@ export interface Stats {
   extendVariant: number; shadowVariant: number; verifyFailed: number;
 }
 export class Renderer {
-  constructor(options?: { device?: number; width?: number; height?: number; options?: TraceOptions });
+  /** `devices: [0, 1, ...]` renders on several GPUs of one node behind one Renderer (include/ptmi.h ptmi_multi_*: rows dealt out as
+   *  interleaved strips, one RCCL gather assembles the frame when it is read, or every `gatherEvery` frames). STATUS: checked with one
+   *  device through RCCL and with several contexts on one device (`loopback: true`); more than one device over RCCL has never run —
+   *  no machine this was built on has two GPUs. */
+  constructor(options?: { device?: number; devices?: number[]; loopback?: boolean; gatherEvery?: number; maxFramesPerTick?: number;
+                          width?: number; height?: number; options?: TraceOptions });
   camera: CameraCPU;
   addOnUpdate(callback: (deltaTime: number) => void): void;
   loadModel(model: string | SceneData | { blobs: SceneBlobs; atlas?: Atlas | null }, atlas?: Atlas): Promise<void>;
