@@ -291,11 +291,6 @@ typedef struct ptmi_image_info {
 int ptmi_debug_build_image(const ptmi_triangle *triangles, uint32_t n_triangles, const ptmi_bvh_node *bvh_nodes, uint32_t n_nodes,
                            const ptmi_options *opt, ptmi_image_info *info, float *wnodes16, uint32_t *qnodes8, float *tripos12,
                            float *leafbox8);
-/* Host only. The device layout of the own triangle images (a leaf that fits one 128-byte line lies in one; leaf references of the
- * node images count float4s into it) checked against the logical image ptmi_debug_build_image returns: out[0] float4s laid out,
- * [1] leaves, [2] leaves that touch more lines than their size needs, [3] references / images that do not match, [4] float4s packed. */
-int ptmi_debug_leaf_layout(const ptmi_triangle *triangles, uint32_t n_triangles, const ptmi_bvh_node *bvh_nodes, uint32_t n_nodes,
-                           const ptmi_options *opt, uint64_t out[5]);
 /* arithmetic-contract probe: out[i] = op(a[i], b[i], c[i]) evaluated on the device.
  * ops: 0 a/b, 1 sqrt(a), 2 fma(a,b,c), 3 min(a,b), 4 max(a,b), 5 sin(a), 6 cos(a),
  *      7 pow5(a), 8 f32(u32 bits of a), 9 u32(a) as bits, 10 a - trunc(a), 11 tan(a), 12 1/a (the kernels' short form) */

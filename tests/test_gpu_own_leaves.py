@@ -51,7 +51,7 @@ def more_rays(sc, n, seed):
     return o, d
 
 
-@pytest.mark.parametrize("name", ["cornell", "feature_box", "cornell_spheres", "grid_1m", "soup_600"])
+@pytest.mark.parametrize("name", ["cornell", "feature_box", "cornell_spheres", "grid_1m"])
 def test_every_memory_variant_returns_the_oracles_hits(own_ctx, oracle, scene_factory, name):
     sc = scene_factory(name)
     own_ctx.upload_scene(sc)
@@ -79,10 +79,9 @@ def test_every_memory_variant_returns_the_oracles_hits(own_ctx, oracle, scene_fa
     st = own_ctx.stats()
     assert st.leaves_used == 2
     # the variants that fit this scene really ran (the others fell back to the library's choice)
-    # (Cornell: 634 nodes — 40 KB exact, 20 KB quantised — and 64 KB of triangle images, a leaf to a line, beside 60 / 64 KB of stacks:
-    # the exact nodes with resident triangles no longer fit; the 600-triangle soup runs them)
+    # (Cornell: 634 nodes — 40 KB exact, 20 KB quantised — and 48 KB of triangles beside 60 / 64 KB of stacks)
     # (cornell_spheres: 2 038 nodes — 64 KB quantised: 8 16-bit entries per lane beside them in half a CU's LDS, in a tree 19 levels deep)
-    want = {"cornell": {51, 61, 72, 71, 81, 91, 102, 112}, "soup_600": {41, 61, 81, 91, 102}, "feature_box": {81, 91, 102, 112}, "cornell_spheres": {71, 81, 91, 112}, "grid_1m": {81, 91}}[name]
+    want = {"cornell": {41, 51, 61, 72, 71, 81, 91, 102, 112}, "feature_box": {81, 91, 102, 112}, "cornell_spheres": {71, 81, 91, 112}, "grid_1m": {81, 91}}[name]
     assert want <= {u for u, _ in ran}, (name, sorted(ran))
     assert want <= {s for _, s in ran}, (name, sorted(ran))
 

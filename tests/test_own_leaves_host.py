@@ -178,22 +178,3 @@ def test_scene_with_a_non_finite_vertex_keeps_the_reference_leaves():
     assert info.leaves_used == 1 and lb is None
     info, *_ = native.build_image(sc, leaves=2, keep_reference_tree=1)
     assert info.leaves_used == 1
-
-
-@pytest.mark.parametrize("name,leaf_tris", [("cornell", 0), ("cornell", 4), ("cornell_spheres", 0), ("feature_box", 8), ("soup3", 3), ("soup3", 0)])
-def test_device_layout_keeps_a_leaf_in_one_line(name, leaf_tris):
-    """What the device gets (csrc/ptmi_api.hip place_leaves): the triangle images of a leaf start at the next 128-byte line whenever
-    they would otherwise touch more lines than their size needs, and the leaf references of both node images count float4s into that
-    array — checked by the library against the logical image the other tests of this file pin down."""
-    sc = scene_of(name)
-    r = native.leaf_layout(sc, leaf_tris)
-    info, *_ = native.build_image(sc, leaves=2, leaf_tris=leaf_tris)
-    assert r["leaves"] == info.n_leaves and r["float4s_packed"] == 3 * info.n_tris
-    assert r["mismatches"] == 0 and r["leaves_over_lines"] == 0
-    assert r["float4s_packed"] <= r["float4s"] <= r["float4s_packed"] * 5 // 3 + 8
-    os.environ["PTMI_TRI_PAD"] = "0"
-    try:
-        p = native.leaf_layout(sc, leaf_tris)
-    finally:
-        del os.environ["PTMI_TRI_PAD"]
-    assert p["mismatches"] == 0 and p["float4s"] == p["float4s_packed"] and (p["leaves_over_lines"] > 0 or info.n_leaves < 3)

@@ -48,10 +48,9 @@ struct DevScene {
     uint32_t q_cached;          // the first q_cached quantised nodes are the top levels in breadth-first order (kept in LDS)
     // OWN LEAVES (ptmi_options.leaves = 2, traverse_own.hip; own = 0: none of this is set). wnodes / tripos / qnodes / root_min / root_max
     // then describe the library's own hierarchy over the triangles: padded boxes, tripos in LEAF order with the original triangle
-    // index in v0.w — own_tri_f4 float4s: a leaf that fits one 128-byte line lies in one (ptmi_api.hip place_leaves), and a leaf
-    // reference of wnodes / qnodes counts FLOAT4s into it, not triangles; qnodes without a leaf stream. The tree as uploaded stays in
-    // ref_wnodes (its exact root box in ref_root_min / _max) with the triangle images in ORIGINAL order in ref_tripos: what `slow` rays walk.
-    uint32_t own, own_tri_f4;
+    // index in v0.w, n_own_tris entries; qnodes without a leaf stream. The tree as uploaded stays in ref_wnodes (its exact root box
+    // in ref_root_min / _max) with the triangle images in ORIGINAL order in ref_tripos: what `slow` rays walk.
+    uint32_t own, n_own_tris;
     const float4 *ref_tripos;
     const float4 *tri_leafbox;  // per ORIGINAL triangle index: (min.xyz, 0), (max.xyz, 0) of the reference leaf that lists it
     float ref_root_min[3], ref_root_max[3];
@@ -61,7 +60,6 @@ struct DevScene {
     const float4 *wnodes16, *ref_wnodes16;
     uint32_t root_ref16, ref_root_ref16;
     const uint4 *qnodes16;      // qnodes with the same 16-bit references (NULL: none)
-    const float4 *tripos16;     // the triangle images those references index: packed, 3 float4s per triangle, leaf order
     unsigned long long *verify_stat;    // += rays whose winner failed its reference leaf's box and were traced again
     const DevScene *self;       // this description in device memory (the own-leaf kernels read it from there, not from kernel arguments)
 };

@@ -57,7 +57,6 @@ struct ptmi_ctx {
     float4 *d_wnodes = nullptr, *d_tripos = nullptr, *d_fast_wnodes = nullptr;
     float4 *d_own_tripos = nullptr, *d_leafbox = nullptr, *d_wnodes16 = nullptr, *d_ref_wnodes16 = nullptr;
     uint4 *d_qnodes16 = nullptr;
-    float4 *d_own_tripos16 = nullptr;     // the own triangle images packed, in leaf order: what the 16-bit references index
     DevScene *d_scene = nullptr;                       // sc in device memory (DevScene::self), rewritten whenever sc changes               // own leaves: leaf-ordered triangle images, per-triangle reference leaf boxes
     uint4 *d_qnodes = nullptr; uint32_t *d_leaf_stream = nullptr;        // quantised image of the rebuilt hierarchy (global variant)
     DevScene sc{};
@@ -238,12 +237,6 @@ struct Built {
     std::vector<float4> leafbox;             // 2 float4 per triangle (original index): its reference leaf's box
     std::vector<float4> own_wnodes16, ref_wnodes16;   // the two hierarchies with 16-bit child references (empty: the scene is too large for them)
     std::vector<uint4> own_qnodes16;         // own_qnodes with 16-bit child references (empty: no quantised image, or too large)
-    // What the device gets for the 32-bit references (place_leaves): the triangle images laid out so that a leaf that fits one 128-byte
-    // line lies in one, and copies of the node images whose leaf references count float4s into that array. (own_tree, own_qnodes and the
-    // 16-bit images keep triangle positions: the packed array, ptmi_debug_build_image, tools/own_sim.c.)
-    std::vector<float4> dev_tripos, dev_wnodes;
-    std::vector<uint4> dev_qnodes;
-    uint32_t dev_root = PT_REF_NONE;
     uint32_t own_root16 = PT_REF_NONE, ref_root16 = PT_REF_NONE;
 };
 
@@ -271,49 +264,6 @@ bool compact_refs(const std::vector<float4> &w, uint32_t root, std::vector<float
         std::memcpy(&out[i * 4 + 3].x, &l16, 4); std::memcpy(&out[i * 4 + 3].y, &r16, 4);
     }
     return true;
-}
-
-// The device layout of the own triangle images. A leaf is 1 - 2 (at most 32) images of 48 bytes; packed back to back, three leaves of
-// four start in one 128-byte line and end in the next, and a kernel that fetches a leaf from memory pays two lines for it (the
-// 1 M-triangle scene: 1.7 lines per leaf visit, most of `extend`'s 9 x algorithmic traffic). Here a leaf starts at the next line
-// whenever it would otherwise touch more lines than its size needs; references count float4s. PTMI_TRI_PAD=0: packed (same-box A/Bs).
-void place_leaves(Built &b) {
-    const PtOwnTree &t = b.own_tree;
-    const char *env = std::getenv("PTMI_TRI_PAD");
-    const bool pad = !(env && env[0] == '0');
-    const size_t n_pos = t.tripos.size() / 3;
-    std::vector<uint32_t> cnt_at(n_pos, 0u);             // leaf starting at position p holds cnt_at[p] triangles
-    auto note = [&](uint32_t r) {
-        if (r != PT_REF_NONE && (r & PT_REF_LEAF)) cnt_at[r & PT_LEAF_OFF_MASK] = ((r >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) + 1u;
-    };
-    note(t.root_ref);
-    for (size_t i = 0; i < t.wnodes.size() / 4; i++) {
-        uint32_t l, r; std::memcpy(&l, &t.wnodes[i * 4 + 3].x, 4); std::memcpy(&r, &t.wnodes[i * 4 + 3].y, 4);
-        note(l); note(r);
-    }
-    std::vector<uint32_t> f4_at(n_pos, 0u);
-    b.dev_tripos.clear(); b.dev_tripos.reserve(t.tripos.size() + t.tripos.size() / 2);
-    for (size_t p = 0; p < n_pos;) {
-        const uint32_t cnt = cnt_at[p] ? cnt_at[p] : 1u;
-        const size_t at = b.dev_tripos.size(), in_line = at & 7u, need = (size_t)cnt * 3;       // float4s: 8 to a line
-        if (pad && in_line && (in_line + need + 7) / 8 > (need + 7) / 8) b.dev_tripos.resize(at + (8 - in_line), make_float4(0, 0, 0, 0));
-        f4_at[p] = (uint32_t)b.dev_tripos.size();
-        b.dev_tripos.insert(b.dev_tripos.end(), t.tripos.begin() + (std::ptrdiff_t)(p * 3), t.tripos.begin() + (std::ptrdiff_t)((p + cnt) * 3));
-        p += cnt;
-    }
-    auto conv = [&](uint32_t r) -> uint32_t {
-        if (r == PT_REF_NONE || !(r & PT_REF_LEAF)) return r;
-        return (r & ~PT_LEAF_OFF_MASK) | f4_at[r & PT_LEAF_OFF_MASK];
-    };
-    b.dev_root = conv(t.root_ref);
-    b.dev_wnodes = t.wnodes;
-    for (size_t i = 0; i < b.dev_wnodes.size() / 4; i++) {
-        uint32_t l, r; std::memcpy(&l, &b.dev_wnodes[i * 4 + 3].x, 4); std::memcpy(&r, &b.dev_wnodes[i * 4 + 3].y, 4);
-        l = conv(l); r = conv(r);
-        std::memcpy(&b.dev_wnodes[i * 4 + 3].x, &l, 4); std::memcpy(&b.dev_wnodes[i * 4 + 3].y, &r, 4);
-    }
-    b.dev_qnodes = b.own_qnodes;
-    for (uint4 &q : b.dev_qnodes) q.w = conv(q.w);
 }
 
 #ifndef PT_LEAVES_DEFAULT
@@ -439,8 +389,6 @@ int build_image(ptmi_ctx *c, const ptmi_triangle *tris, uint32_t nt, const ptmi_
                 b.own_qnodes16 = b.own_qnodes;
                 for (uint4 &q : b.own_qnodes16) if (!compact_ref(q.w, q.w)) { b.own_qnodes16.clear(); break; }
             }
-            if (b.own_tree.tripos.size() + b.own_tree.tripos.size() / 2 + 8 > PT_LEAF_OFF_MASK) { b.own = false; b.leafbox.clear(); }
-            else place_leaves(b);
         } else {
             b.leafbox.clear();
         }
@@ -498,7 +446,7 @@ TraverseConfig own_config(const ptmi_ctx *c, bool closest_hit) {
     cfg.lds_scene_bytes = c->lds_scene_bytes;
     cfg.wgs_per_cu = 1;
     const uint32_t depth = std::max(c->own_depth, c->bvh_depth);      // slow rays walk the uploaded tree on the same stacks
-    const size_t ne = (size_t)c->sc.n_wnodes * 64, nq = (size_t)c->sc.n_wnodes * 32, tb = (size_t)c->sc.own_tri_f4 * 16;
+    const size_t ne = (size_t)c->sc.n_wnodes * 64, nq = (size_t)c->sc.n_wnodes * 32, tb = (size_t)c->sc.n_own_tris * 48;
     const bool quant = c->own_quant;
     const int full_stack = depth + 2 <= 16 ? 16 : depth + 2 <= 32 ? 32 : 0;
     const size_t full_b = (size_t)full_stack * 4096, two_b = (size_t)15 * 4096, spill_b = (size_t)16 * 4096;
@@ -724,7 +672,7 @@ int ptmi_destroy(ptmi_ctx *c) {
     }
     dfree(c->d_tris); dfree(c->d_mats); dfree(c->d_lights); dfree(c->d_atlas); dfree(c->d_wnodes); dfree(c->d_tripos);
     dfree(c->d_fast_wnodes); dfree(c->d_qnodes); dfree(c->d_leaf_stream); dfree(c->d_own_tripos); dfree(c->d_leafbox); dfree(c->d_wnodes16); dfree(c->d_ref_wnodes16);
-    dfree(c->d_qnodes16); dfree(c->d_own_tripos16);
+    dfree(c->d_qnodes16);
     dfree(c->d_out_own); dfree(c->d_stats); dfree(c->d_scene); dfree(c->d_blit_f32); dfree(c->d_blit_u8);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -782,12 +730,12 @@ int pt_install_scene(ptmi_ctx *c, const PtPrepared *prep) {
     const auto t_copy = clk::now();
     void *n_tris = nullptr, *n_mats = nullptr, *n_lights = nullptr;
     float4 *n_wnodes = nullptr, *n_tripos = nullptr, *n_fast = nullptr, *n_own_tripos = nullptr, *n_leafbox = nullptr;
-    float4 *n_w16 = nullptr, *n_r16 = nullptr, *n_t16 = nullptr;
+    float4 *n_w16 = nullptr, *n_r16 = nullptr;
     const bool has16 = b.own && !b.own_wnodes16.empty();
     uint4 *n_qnodes = nullptr, *n_q16 = nullptr; uint32_t *n_stream = nullptr;
     const bool own = b.own;
     const bool hasq16 = has16 && !b.own_qnodes16.empty();
-    const std::vector<uint4> &qn = own ? b.dev_qnodes : b.qnodes;
+    const std::vector<uint4> &qn = own ? b.own_qnodes : b.qnodes;
     const bool quant = !qn.empty();
     auto up = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
         if (bytes == 0) { hipError_t e = hipMalloc(dst, 16); if (e != hipSuccess) return e; return hipMemset(*dst, 0, 16); }
@@ -795,7 +743,7 @@ int pt_install_scene(ptmi_ctx *c, const PtPrepared *prep) {
         return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     };
     // n_fast: the hierarchy the regular rays walk when it is not the uploaded one — rebuilt over the reference's leaves, or the own tree
-    const std::vector<float4> &walk = own ? b.dev_wnodes : b.fast_wnodes;
+    const std::vector<float4> &walk = own ? b.own_tree.wnodes : b.fast_wnodes;
     const bool fast = own || !b.fast_wnodes.empty();
     hipError_t e = up(&n_tris, tris, (size_t)nt * sizeof(ptmi_triangle));
     if (e == hipSuccess) e = up(&n_mats, mats, (size_t)nm * sizeof(ptmi_material));
@@ -803,8 +751,7 @@ int pt_install_scene(ptmi_ctx *c, const PtPrepared *prep) {
     if (e == hipSuccess) e = up(reinterpret_cast<void **>(&n_wnodes), b.wnodes.data(), b.wnodes.size() * 16);
     if (e == hipSuccess) e = up(reinterpret_cast<void **>(&n_tripos), b.tripos.data(), b.tripos.size() * 16);
     if (e == hipSuccess && fast) e = up(reinterpret_cast<void **>(&n_fast), walk.data(), walk.size() * 16);
-    if (e == hipSuccess && own) e = up(reinterpret_cast<void **>(&n_own_tripos), b.dev_tripos.data(), b.dev_tripos.size() * 16);
-    if (e == hipSuccess && has16) e = up(reinterpret_cast<void **>(&n_t16), b.own_tree.tripos.data(), b.own_tree.tripos.size() * 16);
+    if (e == hipSuccess && own) e = up(reinterpret_cast<void **>(&n_own_tripos), b.own_tree.tripos.data(), b.own_tree.tripos.size() * 16);
     if (e == hipSuccess && own) e = up(reinterpret_cast<void **>(&n_leafbox), b.leafbox.data(), b.leafbox.size() * 16);
     if (e == hipSuccess && has16) e = up(reinterpret_cast<void **>(&n_w16), b.own_wnodes16.data(), b.own_wnodes16.size() * 16);
     if (e == hipSuccess && has16) e = up(reinterpret_cast<void **>(&n_r16), b.ref_wnodes16.data(), b.ref_wnodes16.size() * 16);
@@ -813,7 +760,7 @@ int pt_install_scene(ptmi_ctx *c, const PtPrepared *prep) {
     if (e == hipSuccess && quant && !own) e = up(reinterpret_cast<void **>(&n_stream), b.leaf_stream.data(), b.leaf_stream.size() * 4);
     if (e != hipSuccess) {
         dfree(n_tris); dfree(n_mats); dfree(n_lights); dfree(n_wnodes); dfree(n_tripos); dfree(n_fast); dfree(n_qnodes); dfree(n_stream);
-        dfree(n_own_tripos); dfree(n_leafbox); dfree(n_w16); dfree(n_r16); dfree(n_q16); dfree(n_t16);
+        dfree(n_own_tripos); dfree(n_leafbox); dfree(n_w16); dfree(n_r16); dfree(n_q16);
         return fail(c, PTMI_E_HIP, "scene upload failed: %s (the previous scene, if any, is still in place)", hipGetErrorString(e));
     }
     HIP_TRY(c, sync_all(c));                  // nothing in flight reads the old buffers any more
@@ -821,7 +768,6 @@ int pt_install_scene(ptmi_ctx *c, const PtPrepared *prep) {
     dfree(c->d_qnodes); dfree(c->d_leaf_stream); dfree(c->d_own_tripos); dfree(c->d_leafbox); dfree(c->d_wnodes16); dfree(c->d_ref_wnodes16);
     c->d_wnodes16 = n_w16; c->d_ref_wnodes16 = n_r16;
     dfree(c->d_qnodes16); c->d_qnodes16 = n_q16;
-    dfree(c->d_own_tripos16); c->d_own_tripos16 = n_t16;
     c->d_qnodes = n_qnodes; c->d_leaf_stream = n_stream;
     c->d_tris = n_tris; c->d_mats = n_mats; c->d_lights = n_lights;
     c->d_wnodes = n_wnodes; c->d_tripos = n_tripos; c->d_fast_wnodes = n_fast;
@@ -843,10 +789,9 @@ int pt_install_scene(ptmi_ctx *c, const PtPrepared *prep) {
         s.ref_root_min[k] = b.root_min[k]; s.ref_root_max[k] = b.root_max[k];
         s.root_min[k] = own ? b.own_tree.root_min[k] : b.root_min[k]; s.root_max[k] = own ? b.own_tree.root_max[k] : b.root_max[k];
     }
-    s.root_ref = own ? b.dev_root : fast ? b.fast_root : b.root_ref;
+    s.root_ref = own ? b.own_tree.root_ref : fast ? b.fast_root : b.root_ref;
     s.own = own ? 1u : 0u;
-    s.own_tri_f4 = own ? (uint32_t)b.dev_tripos.size() : 0u;
-    s.tripos16 = c->d_own_tripos16;
+    s.n_own_tris = own ? (uint32_t)(b.own_tree.tripos.size() / 3) : 0u;
     s.tri_leafbox = c->d_leafbox;
     s.wnodes16 = c->d_wnodes16; s.ref_wnodes16 = c->d_ref_wnodes16; s.qnodes16 = c->d_qnodes16;
     s.root_ref16 = has16 ? b.own_root16 : PT_REF_NONE; s.ref_root_ref16 = has16 ? b.ref_root16 : PT_REF_NONE;
@@ -857,7 +802,7 @@ int pt_install_scene(ptmi_ctx *c, const PtPrepared *prep) {
     c->bvh_depth = std::max(b.depth, b.fast_depth);           // stacks must hold either tree (irregular rays use the uploaded one)
     c->own_depth = own ? b.own_tree.depth : 0u;
     c->own_quant = own && quant;
-    c->lds_scene_bytes = (size_t)s.n_wnodes * 64 + (own ? b.dev_tripos.size() : b.tripos.size()) * 16;
+    c->lds_scene_bytes = (size_t)s.n_wnodes * 64 + (own ? b.own_tree.tripos.size() : b.tripos.size()) * 16;
     c->have_scene = true;
     c->st.leaves_used = own ? 2u : 1u;
     c->st.leaf_tris_used = own ? b.own_tree.max_leaf_tris : b.max_leaf_tris;
@@ -1374,50 +1319,6 @@ int ptmi_debug_build_image(const ptmi_triangle *tris, uint32_t nt, const ptmi_bv
     if (qnodes8 && !qn.empty()) std::memcpy(qnodes8, qn.data(), qn.size() * 16);
     if (tripos12 && !tp.empty()) std::memcpy(tripos12, tp.data(), tp.size() * 16);
     if (leafbox8 && !b.leafbox.empty()) std::memcpy(leafbox8, b.leafbox.data(), b.leafbox.size() * 16);
-    return PTMI_OK;
-}
-
-// The device layout of the own triangle images (place_leaves) checked against the logical image it was made from. out[0] = float4s of
-// the laid-out array, [1] = leaves, [2] = leaves that touch more 128-byte lines than their size needs, [3] = leaf references (exact and
-// quantised node images, root) whose count or images differ from the logical leaf's, [4] = float4s of the packed array.
-int ptmi_debug_leaf_layout(const ptmi_triangle *tris, uint32_t nt, const ptmi_bvh_node *nodes, uint32_t nn, const ptmi_options *opt, uint64_t out[5]) {
-    if (!out || (nt && !tris) || (nn && !nodes)) return PTMI_E_INVALID;
-    for (int i = 0; i < 5; i++) out[i] = 0;
-    ptmi_ctx tmp;
-    default_options(tmp.opt);
-    tmp.opt.leaves = 2;
-    if (opt) tmp.opt.leaf_tris = opt->leaf_tris;
-    Built b;
-    int rc = build_image(&tmp, tris, nt, nodes, nn, b);
-    if (rc) { g_create_err = tmp.err; return rc; }
-    if (!b.own) return PTMI_OK;
-    const PtOwnTree &t = b.own_tree;
-    out[0] = b.dev_tripos.size(); out[4] = t.tripos.size();
-    auto check = [&](uint32_t logical, uint32_t dev, bool count_leaf) {
-        if ((logical & PT_REF_LEAF) != (dev & PT_REF_LEAF) || logical == PT_REF_NONE) { if (logical != dev) out[3]++; return; }
-        if (!(logical & PT_REF_LEAF)) { if (logical != dev) out[3]++; return; }
-        const uint32_t cnt = ((logical >> PT_LEAF_OFF_BITS) & (PT_LEAF_MAX_TRIS - 1u)) + 1u, first = logical & PT_LEAF_OFF_MASK, at = dev & PT_LEAF_OFF_MASK;
-        if ((dev >> PT_LEAF_OFF_BITS) != (logical >> PT_LEAF_OFF_BITS) || (size_t)at + 3u * cnt > b.dev_tripos.size() ||
-            std::memcmp(&b.dev_tripos[at], &t.tripos[(size_t)first * 3], (size_t)cnt * 48) != 0) { out[3]++; return; }
-        if (count_leaf) {
-            out[1]++;
-            const size_t need = (size_t)cnt * 3, in_line = at & 7u;
-            if ((in_line + need + 7) / 8 > (need + 7) / 8) out[2]++;
-        }
-    };
-    check(t.root_ref, b.dev_root, (t.root_ref & PT_REF_LEAF) != 0);
-    if (b.dev_wnodes.size() != t.wnodes.size() || b.dev_qnodes.size() != b.own_qnodes.size()) { out[3]++; return PTMI_OK; }
-    for (size_t i = 0; i < t.wnodes.size() / 4; i++) {
-        uint32_t l, r, dl, dr;
-        std::memcpy(&l, &t.wnodes[i * 4 + 3].x, 4); std::memcpy(&r, &t.wnodes[i * 4 + 3].y, 4);
-        std::memcpy(&dl, &b.dev_wnodes[i * 4 + 3].x, 4); std::memcpy(&dr, &b.dev_wnodes[i * 4 + 3].y, 4);
-        check(l, dl, true); check(r, dr, true);
-        if (std::memcmp(&t.wnodes[i * 4], &b.dev_wnodes[i * 4], 48) != 0) out[3]++;
-    }
-    for (size_t i = 0; i < b.own_qnodes.size(); i++) {
-        check(b.own_qnodes[i].w, b.dev_qnodes[i].w, false);
-        if (b.own_qnodes[i].x != b.dev_qnodes[i].x || b.own_qnodes[i].y != b.dev_qnodes[i].y || b.own_qnodes[i].z != b.dev_qnodes[i].z) out[3]++;
-    }
     return PTMI_OK;
 }
 

@@ -67,7 +67,7 @@ PT_DEV v3 rcp3(v3 d) { return mk3(rcp1(d.x), rcp1(d.y), rcp1(d.z)); }
 // ---- node / triangle access policies ---------------------------------------------------------------------------------
 // Pre            : what a ray keeps for the box tests (computed once per ray by prep)
 // test(i, pre..) : both child boxes of node i against the ray: entry distances, verdicts, child references
-// tri(i, a, b, c): (v0, original index), e1, e2 of the triangle whose image starts at float4 i of the leaf-ordered array
+// tri(i, a, b, c): (v0, original index), e1, e2 of the triangle at position i of the leaf-ordered image
 template <bool TRIS_IN_LDS>
 struct OwnLdsMem {
     lds_f4p wn, tl; glb_f4p tg;
@@ -81,8 +81,8 @@ struct OwnLdsMem {
         lref = __float_as_uint(r.x); rref = __float_as_uint(r.y);
     }
     PT_DEV void tri(uint32_t i, float4 &a, float4 &b, float4 &c) const {
-        if (TRIS_IN_LDS) { lds_f4p p = tl + i; a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]); }
-        else { glb_f4p p = tg + (size_t)i; a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]); }
+        if (TRIS_IN_LDS) { lds_f4p p = tl + 3u * i; a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]); }
+        else { glb_f4p p = tg + 3u * (size_t)i; a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]); }
     }
 };
 struct OwnGlobalMem {
@@ -96,7 +96,7 @@ struct OwnGlobalMem {
         lref = __float_as_uint(r.x); rref = __float_as_uint(r.y);
     }
     PT_DEV void tri(uint32_t i, float4 &a, float4 &b, float4 &c) const {
-        glb_f4p p = tg + (size_t)i; a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]);
+        glb_f4p p = tg + 3u * (size_t)i; a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]);
     }
 };
 // Quantised nodes (fast_tree.hip pt_quantize_nodes): per child three words of 16-bit plane numbers (lo.x | lo.y << 16,
@@ -125,8 +125,8 @@ struct OwnQuantMem {
         lref = l.w; rref = r.w;
     }
     PT_DEV void tri(uint32_t i, float4 &a, float4 &b, float4 &c) const {
-        if (TRIS_IN_LDS) { lds_f4p p = tl + i; a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]); }
-        else { glb_f4p p = tg + (size_t)i; a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]); }
+        if (TRIS_IN_LDS) { lds_f4p p = tl + 3u * i; a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]); }
+        else { glb_f4p p = tg + 3u * (size_t)i; a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]); }
     }
 };
 
@@ -285,17 +285,14 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
                     lp += stride;                                       // next filed leaf
                     uint32_t first, cnt;
                     open_leaf(*lp, first, cnt);
-                    // where the leaf's images start, in float4s: the own image's 32-bit references say so themselves; 16-bit ones and the
-                    // uploaded tree's count triangles (of the packed / the original array)
-                    const uint32_t base = (old || R16) ? 3u * first : first;
                     for (uint32_t k = 0; k < cnt; k++) {                // pt.wgsl:272-279
                         UTIL(8, uniform(lane) == lane ? 1 : 0); UTIL(9, 1);
                         float4 a, b, c;
                         if (old) {
-                            glb_f4p p = (glb_f4p)sc.ref_tripos + (size_t)(base + 3u * k);
+                            glb_f4p p = (glb_f4p)sc.ref_tripos + 3u * (size_t)(first + k);
                             a = as_f4(p[0]); b = as_f4(p[1]); c = as_f4(p[2]);
                         } else {
-                            m.tri(base + 3u * k, a, b, c);
+                            m.tri(first + k, a, b, c);
                         }
                         float u = 0.0f, v = 0.0f;
                         const float t = tri_test_t<!REF>(xyz(a), xyz(b), xyz(c), o, d, u, v);
@@ -413,7 +410,7 @@ __global__ __launch_bounds__(LBLOCK) __attribute__((amdgpu_waves_per_eu((STACK =
     extern __shared__ float4 smem[];
     const uint32_t count = *count_ptr;
     if (blockIdx.x * 64u >= count) return;      // wave 0 owns group blockIdx.x; if that is empty the whole group is idle
-    const uint32_t nw = ((LAYOUT == 1 || LAYOUT == 3) ? 2u : 4u) * sc.n_wnodes, nt = TRIS ? sc.own_tri_f4 : 0u;
+    const uint32_t nw = ((LAYOUT == 1 || LAYOUT == 3) ? 2u : 4u) * sc.n_wnodes, nt = TRIS ? 3u * sc.n_own_tris : 0u;
     const float4 *src = LAYOUT == 1 ? reinterpret_cast<const float4 *>(sc.qnodes) : LAYOUT == 3 ? reinterpret_cast<const float4 *>(sc.qnodes16)
                       : LAYOUT == 2 ? sc.wnodes16 : sc.wnodes;
     for (uint32_t i = threadIdx.x; i < nw; i += LBLOCK) smem[i] = src[i];
@@ -424,12 +421,11 @@ __global__ __launch_bounds__(LBLOCK) __attribute__((amdgpu_waves_per_eu((STACK =
     uint32_t *stk = reinterpret_cast<uint32_t *>(smem + nw + nt) + threadIdx.x;
     uint32_t *sp = SPILL ? spill + (size_t)blockIdx.x * LBLOCK + threadIdx.x : nullptr;
     if constexpr (LAYOUT == 2) {
-        static_assert(!TRIS, "the 16-bit references index the packed array, which is never staged");
-        OwnLdsMem<TRIS> m{(lds_f4p)smem, (lds_f4p)(smem + nw), (glb_f4p)sc.tripos16};
+        OwnLdsMem<TRIS> m{(lds_f4p)smem, (lds_f4p)(smem + nw), (glb_f4p)sc.tripos};
         uint16_t *stk16 = reinterpret_cast<uint16_t *>(smem + nw + nt) + threadIdx.x;
         trace_wave_own<MODE, CULL, STACK, false, PT_OWN_REFILL_AT>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk16, LBLOCK);
     } else if constexpr (LAYOUT == 3) {
-        OwnQuantMem<true, false> m{(lds_u4p)smem, (glb_u4p)sc.qnodes16, sc.n_wnodes, (lds_f4p)nullptr, (glb_f4p)sc.tripos16,
+        OwnQuantMem<true, false> m{(lds_u4p)smem, (glb_u4p)sc.qnodes16, sc.n_wnodes, (lds_f4p)nullptr, (glb_f4p)sc.tripos,
                                    sc.q_origin[0], sc.q_origin[1], sc.q_origin[2], sc.q_scale[0], sc.q_scale[1], sc.q_scale[2]};
         uint16_t *stk16 = reinterpret_cast<uint16_t *>(smem + nw + nt) + threadIdx.x;
         trace_wave_own<MODE, CULL, 0, true, PT_OWN_REFILL_AT>(m, sc, io, count, gw, gridDim.x * (LBLOCK / 64), stk16, LBLOCK, sp, gridDim.x * LBLOCK, nstack);
@@ -498,7 +494,7 @@ void launch_own(hipStream_t s, int blocks, const TraverseConfig &cfg, const DevS
     const int cus = blocks / 8 > 0 ? blocks / 8 : 1;
     const DevScene *sc = hsc.self;              // the kernels read the description from device memory
     const size_t node_bytes = (size_t)hsc.n_wnodes * (cfg.variant == PT_VARIANT_OWN_LDS || cfg.variant == PT_VARIANT_OWN_LDS_NODES || cfg.variant == PT_VARIANT_OWN_LDS16_NODES ? 64 : 32);
-    const size_t tri_bytes = (size_t)hsc.own_tri_f4 * 16;
+    const size_t tri_bytes = (size_t)hsc.n_own_tris * 48;
     const size_t stack_bytes = (size_t)cfg.stack_entries * LBLOCK * sizeof(uint32_t);
     switch (cfg.variant) {
     case PT_VARIANT_OWN_LDS:                    // exact nodes + triangles resident, one workgroup per CU

@@ -22,7 +22,7 @@ EXPORTS = [
     "ptmi_synchronize", "ptmi_read_output", "ptmi_write_output", "ptmi_output_device_ptr",
     "ptmi_bind_output_device", "ptmi_set_stream", "ptmi_blit", "ptmi_get_stats", "ptmi_reset_stats",
     "ptmi_debug_raygen", "ptmi_debug_intersect", "ptmi_debug_occluded", "ptmi_debug_math", "ptmi_debug_exact_math", "ptmi_get_size",
-    "ptmi_debug_image_stats", "ptmi_debug_build_image", "ptmi_debug_leaf_layout", "ptmi_throttle", "ptmi_multi_throttle",
+    "ptmi_debug_image_stats", "ptmi_debug_build_image", "ptmi_throttle", "ptmi_multi_throttle",
     "ptmi_multi_create", "ptmi_multi_destroy", "ptmi_multi_last_error", "ptmi_multi_count", "ptmi_multi_context",
     "ptmi_multi_upload_scene", "ptmi_multi_upload_atlas", "ptmi_multi_resize", "ptmi_multi_set_options", "ptmi_multi_get_options",
     "ptmi_multi_dispatch", "ptmi_multi_gather", "ptmi_multi_synchronize", "ptmi_multi_read_output", "ptmi_multi_write_output",
@@ -104,7 +104,6 @@ def load():
         L.ptmi_get_size.argtypes = [vp, vp, vp]
         L.ptmi_debug_image_stats.argtypes = [vp, u32, vp, u32, vp]
         L.ptmi_debug_build_image.argtypes = [vp, u32, vp, u32, vp, vp, vp, vp, vp, vp]
-        L.ptmi_debug_leaf_layout.argtypes = [vp, u32, vp, u32, vp, vp]
         if L.ptmi_abi_version() != ABI_VERSION:
             raise PtmiError(-1, f"{LIB_PATH} has ABI {L.ptmi_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
         L.ptmi_get_stats.argtypes = [vp, vp]
@@ -183,19 +182,6 @@ def build_image(scene, leaves=0, leaf_tris=0, keep_reference_tree=0):
     if rc != 0:
         raise PtmiError(rc, L.ptmi_last_error(None).decode())
     return info, wn, qn, tp, lb
-
-
-def leaf_layout(scene, leaf_tris=0):
-    """Host-only (include/ptmi.h: ptmi_debug_leaf_layout): the device layout of the own triangle images checked against the logical
-    image: dict(float4s, leaves, leaves_over_lines, mismatches, float4s_packed)."""
-    L = load()
-    o = Options()
-    o.leaf_tris = leaf_tris
-    out = (ctypes.c_uint64 * 5)()
-    rc = L.ptmi_debug_leaf_layout(_p(scene.tris), len(scene.tris), _p(scene.nodes), len(scene.nodes), ctypes.byref(o), out)
-    if rc != 0:
-        raise PtmiError(rc, L.ptmi_last_error(None).decode())
-    return dict(float4s=int(out[0]), leaves=int(out[1]), leaves_over_lines=int(out[2]), mismatches=int(out[3]), float4s_packed=int(out[4]))
 
 
 class Context:

@@ -375,8 +375,7 @@ def cornell_enclosed():
 
 
 SCENES = {"cornell": cornell, "cornell_glass": lambda: cornell(glass=True), "cornell_enclosed": cornell_enclosed,
-          "cornell_spheres": cornell_spheres, "grid_1m": grid_1m, "feature_box": feature_box, "deep_chain": deep_chain,
-          "soup_600": lambda: random_soup(11, n_tris=600)}
+          "cornell_spheres": cornell_spheres, "grid_1m": grid_1m, "feature_box": feature_box, "deep_chain": deep_chain}
 
 
 def make(name):
