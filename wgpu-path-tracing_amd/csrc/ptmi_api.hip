@@ -963,17 +963,8 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
                 const uint32_t *q = b == 0 ? nullptr : ln.queue[cur];      // bounce 0: slot i holds path i
                 const int par = side ? (int)(b & 1u) : 0;
                 const ShadeParams shp{b, maxb, c->opt.do_mis, c->d_stats, side ? 1u : 0u};
+                { Timed t(c, 1, t2, ms); (c->sc.own ? pt_launch_extend_own : pt_launch_extend)(ms, blocks, cfg, c->sc, bp, q, &ln.counts[b], ln.hits); }
                 const bool last = b + 1 == maxb;
-#ifdef PT_GRID_SPLIT_AB
-                // A/B only: the persistent grids of the two streams sized to shares of the CUs, so that both are resident at once
-                static const int pct_e = std::getenv("PTMI_EXTEND_CU_PCT") ? std::atoi(std::getenv("PTMI_EXTEND_CU_PCT")) : 100;
-                static const int pct_s = std::getenv("PTMI_SHADOW_CU_PCT") ? std::atoi(std::getenv("PTMI_SHADOW_CU_PCT")) : 100;
-                const int blocks_e = (side && nee && b >= 1) ? std::max(8, c->n_cu * pct_e / 100 * 8) : blocks;
-                const int blocks_s = (side && !last) ? std::max(8, c->n_cu * pct_s / 100 * 8) : blocks;
-#else
-                const int blocks_e = blocks, blocks_s = blocks;
-#endif
-                { Timed t(c, 1, t2, ms); (c->sc.own ? pt_launch_extend_own : pt_launch_extend)(ms, blocks_e, cfg, c->sc, bp, q, &ln.counts[b], ln.hits); }
                 if (side && b >= 2) HIP_TRY(c, hipStreamWaitEvent(ms, ln.ev_shadow[par], 0));      // its records are read
                 { Timed t(c, 2, t3, ms);
                   (c->opt.perf_mode ? pt_launch_shade_fast : pt_launch_shade)(
@@ -986,7 +977,7 @@ int ptmi_dispatch(ptmi_ctx *c, const ptmi_camera *cam, uint32_t n_frames) {
                     HIP_TRY(c, hipEventRecord(ln.ev_ready, ms));
                     HIP_TRY(c, hipStreamWaitEvent(ss, ln.ev_ready, 0));
                     { Timed t(c, 3, t3, ss);
-                      (c->sc.own ? pt_launch_shadow_own : pt_launch_shadow)(ss, blocks_s, cfg_shadow, c->sc, bp, ln.sh[par], ln.sq[par],
+                      (c->sc.own ? pt_launch_shadow_own : pt_launch_shadow)(ss, blocks, cfg_shadow, c->sc, bp, ln.sh[par], ln.sq[par],
                                                                             &ln.counts[kShadowCount + par], nullptr); }
                     HIP_TRY(c, hipEventRecord(ln.ev_shadow[par], ss));
                 } else if (nee) {
