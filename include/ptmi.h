@@ -248,7 +248,8 @@ int ptmi_multi_blit(ptmi_multi *m, float *dst_rgba_f32, size_t n_floats, uint8_t
 /* counters summed over the devices; times (gpu_ms, *_ms) are the maximum over the devices; the rest is device 0's */
 int ptmi_multi_get_stats(ptmi_multi *m, ptmi_stats *out);
 int ptmi_multi_reset_stats(ptmi_multi *m);
-/* time of the last ptmi_multi_gather on device 0's stream, pack + collective + unpack, in ms (-1 before the first; synchronises) */
+/* time of the last ptmi_multi_gather on device 0's stream — from the moment every device has rendered its rows: pack + collective +
+ * unpack, not the wait for the slowest device — in ms (-1 before the first; synchronises) */
 int ptmi_multi_gather_ms(ptmi_multi *m, double *ms);
 
 /* ---- statistics ----------------------------------------------------------- */

@@ -13,7 +13,7 @@ if tag >= "r04":
              3: ("3", "1 M-triangle displaced grid, 1920×1080, 64 spp"),
              4: ("4", "Cornell, 3840×2160, 256 spp, depth of field, whole frame on ONE GPU"),
              0: ("0", "Cornell, 256×256, 16 spp, 4 bounces, MIS off")}
-    var = {102: "exact nodes, 16-bit references, 2 workgroups per CU", 72: "quantised nodes in LDS, 2 workgroups per CU", 71: "quantised nodes in LDS, 1 workgroup per CU, spilling stacks",
+    var = {102: "exact nodes, 16-bit references, 2 workgroups per CU", 112: "quantised nodes, 16-bit references, 2 workgroups per CU, 8 spilling entries", 72: "quantised nodes in LDS, 2 workgroups per CU", 71: "quantised nodes in LDS, 1 workgroup per CU, spilling stacks",
            81: "quantised nodes from memory, top of the tree in LDS", 41: "exact nodes + triangles in LDS, 1 workgroup per CU", 91: "exact nodes from memory"}
     out = ["## Headline (one GPU; all from one box and one session)", "",
            "| config | scene, frame, spp | Msamples/s, own leaves (default) | same run, reference leaves (`leaves_compare`) | gain | device time per step | vector-ALU issue at nominal clock | lanes active per VALU instruction: extend / shadow / shade | extend / shadow variant | CPU oracle (threads) |",

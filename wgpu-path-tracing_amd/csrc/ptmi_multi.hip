@@ -75,6 +75,7 @@ struct ptmi_multi {
     std::vector<float4 *> d_send;                      // per device: its packed rows
     float4 *d_recv = nullptr;                          // device 0: N shares
     std::vector<hipEvent_t> ev;                        // loopback: device r's share is packed
+    std::vector<hipEvent_t> ev_done;                   // device r's rendering is done (recorded on its stream when a gather starts)
     std::vector<hipEvent_t> ev_copied;                 // loopback: device r's share has been copied out of d_send[r] (recorded on device 0's stream)
     std::vector<char> copied_recorded;
     hipEvent_t g0 = nullptr, g1 = nullptr;             // around the last gather on device 0's stream
@@ -201,9 +202,10 @@ int ptmi_multi_create(int n, const int *ordinals, uint32_t flags, ptmi_multi **o
         }
     }
     bool ok = true;
-    m->ev.assign(n, nullptr); m->ev_copied.assign(n, nullptr); m->copied_recorded.assign(n, 0);
+    m->ev.assign(n, nullptr); m->ev_copied.assign(n, nullptr); m->ev_done.assign(n, nullptr); m->copied_recorded.assign(n, 0);
     for (int i = 0; i < n && ok; i++) {
-        ok = hipSetDevice(m->dev[i]) == hipSuccess && hipEventCreateWithFlags(&m->ev[i], hipEventDisableTiming) == hipSuccess;
+        ok = hipSetDevice(m->dev[i]) == hipSuccess && hipEventCreateWithFlags(&m->ev[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&m->ev_done[i], hipEventDisableTiming) == hipSuccess;
         ok = ok && hipSetDevice(m->dev[0]) == hipSuccess && hipEventCreateWithFlags(&m->ev_copied[i], hipEventDisableTiming) == hipSuccess;
     }
     ok = ok && hipSetDevice(m->dev[0]) == hipSuccess && hipEventCreate(&m->g0) == hipSuccess && hipEventCreate(&m->g1) == hipSuccess;
@@ -220,6 +222,7 @@ int ptmi_multi_destroy(ptmi_multi *m) {
     for (ncclComm_t c : m->comm) if (c) (void)g_rccl.CommDestroy(c);
     free_buffers(m);
     for (size_t i = 0; i < m->ev.size(); i++) if (m->ev[i]) { (void)hipSetDevice(m->dev[i]); (void)hipEventDestroy(m->ev[i]); }
+    for (size_t i = 0; i < m->ev_done.size(); i++) if (m->ev_done[i]) { (void)hipSetDevice(m->dev[i]); (void)hipEventDestroy(m->ev_done[i]); }
     for (size_t i = 0; i < m->ev_copied.size(); i++) if (m->ev_copied[i]) { (void)hipSetDevice(m->dev[0]); (void)hipEventDestroy(m->ev_copied[i]); }
     if (m->g0) (void)hipEventDestroy(m->g0);
     if (m->g1) (void)hipEventDestroy(m->g1);
@@ -330,6 +333,14 @@ int ptmi_multi_gather(ptmi_multi *m) {
     }
     const size_t share_f4 = m->rows_max * m->W;
     hipStream_t s0 = pt_ctx_stream(m->ctx[0]);
+    // the timed region (ptmi_multi_gather_ms) starts when EVERY device has rendered its rows: pack, gather, unpack — not the wait for
+    // the slowest device, which is the dispatch's time
+    for (int i = 1; i < n; i++) {
+        MHIP(m, hipSetDevice(m->dev[i]));
+        MHIP(m, hipEventRecord(m->ev_done[i], pt_ctx_stream(m->ctx[i])));
+        MHIP(m, hipSetDevice(m->dev[0]));
+        MHIP(m, hipStreamWaitEvent(s0, m->ev_done[i], 0));
+    }
     MHIP(m, hipSetDevice(m->dev[0]));
     MHIP(m, hipEventRecord(m->g0, s0));
     std::vector<DevBand> bands(n);
