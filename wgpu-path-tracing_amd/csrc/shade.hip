@@ -108,14 +108,6 @@ PT_DEV HitInfo make_hitinfo(const DevScene &sc, v3 ro, v3 rd, float t, uint32_t 
     return hi;
 }
 
-PT_DEV v3 random_cosine_direction(uint32_t &rng) {             // pt.wgsl:299-307
-    float r1 = rng_f(rng), r2 = rng_f(rng);
-    float z = sqrt1(1.0f - r2);
-    float phi = (2.0f * PT_PI) * r1;
-    float sp, cp; sincos1(phi, sp, cp);
-    float sr = sqrt1(r2);
-    return mk3(cp * sr, sp * sr, z);
-}
 PT_DEV float distribution_ggx(v3 N, v3 H, float roughness) {   // pt.wgsl:316-325
     float a = roughness * roughness;
     float a2 = a * a;
@@ -151,46 +143,47 @@ PT_DEV void construct_tbn(v3 N, v3 &T, v3 &B) {                 // pt.wgsl:624-6
     B = normalize3(cross3(N, T));
     T = normalize3(cross3(B, N));
 }
-PT_DEV v3 sample_ggx_normal(uint32_t &rng, v3 normal, float roughness) {   // pt.wgsl:348-364
-    float r1 = rng_f(rng), r2 = rng_f(rng);
+// sampleGGXNormal, pt.wgsl:348-364, from its two draws' products: (sin, cos) of 2 pi r1, r2, and the frame constructTBN gives for `normal`
+PT_DEV v3 ggx_normal_from(float sp, float cp, float r2, v3 normal, v3 T, v3 B, float roughness) {
     float a = roughness * roughness;
-    float phi = (2.0f * PT_PI) * r1;
     float cos_t = sqrt1((1.0f - r2) / (1.0f + (a * a - 1.0f) * r2));
     float sin_t = sqrt1(1.0f - cos_t * cos_t);
-    float sp, cp; sincos1(phi, sp, cp);
-    v3 T, B; construct_tbn(normal, T, B);
     return normalize3(lincomb3(T, sin_t * cp, B, sin_t * sp, normal, cos_t));
 }
 PT_DEV float power_heuristic(float nf, float fpdf, float ng, float gpdf) { // pt.wgsl:492-496
     float f = nf * fpdf, g = ng * gpdf;
     return (f * f) / (f * f + g * g);
 }
-// sampleBSDF, pt.wgsl:498-546
+// sampleBSDF, pt.wgsl:498-546. The three lobes of the reference each start the same way — two draws, (sin, cos) of 2 pi r1, the frame
+// constructTBN builds around the shading normal (randomCosineDirection + constructTBN :299-307 / :624-634 for the diffuse lobe,
+// sampleGGXNormal :348-364 for the other two) — and a wave of bounce rays holds lanes of all three: written lobe by lobe it would
+// execute that prefix three times and the GGX half-vector twice, each time for a part of its lanes. Here the common part runs once for
+// the whole wave and the GGX half-vector once for the specular and the transmissive lanes together: the same operations on the same
+// operands in the same order for every lane (bit-identical results, same RNG draws), a fifth fewer instructions for a mixed wave.
 PT_DEV v3 sample_bsdf(uint32_t &rng, const HitInfo &h, v3 rd, bool front) {
     v3 V = neg3(normalize3(rd));
     float diffuse_p = (1.0f - h.metallic) * (1.0f - h.transmission);
     float specular_p = h.metallic;
     float r = rng_f(rng);
-    if (r < diffuse_p) {
-        v3 l = random_cosine_direction(rng);
-        v3 T, B; construct_tbn(h.normal, T, B);
-        return lincomb3(T, l.x, B, l.y, h.normal, l.z);
-    } else if (r < diffuse_p + specular_p) {
-        float rough = max1(h.roughness, 0.04f);
-        v3 N = sample_ggx_normal(rng, h.normal, rough);
-        return reflect3(neg3(V), N);
-    } else {
-        float eta = front ? rcp1(h.ior) : h.ior;
-        float rough = max1(h.roughness, 0.04f);
-        v3 N = sample_ggx_normal(rng, h.normal, rough);
-        if (!front) N = neg3(N);
-        float cos_t = dot3(N, V);
-        float sin_t = sqrt1(1.0f - cos_t * cos_t);
-        bool cannot_refract = eta * sin_t > 1.0f;
-        float F = reflectance(__builtin_fabsf(cos_t), eta);
-        if (cannot_refract || (rng_f(rng) < F)) return reflect3(neg3(V), N);   // short-circuit: draw only if needed
-        return refract3(neg3(V), N, eta);
+    const float r1 = rng_f(rng), r2 = rng_f(rng);
+    const float phi = (2.0f * PT_PI) * r1;
+    float sp, cp; sincos1(phi, sp, cp);
+    v3 T, B; construct_tbn(h.normal, T, B);
+    if (r < diffuse_p) {                                            // randomCosineDirection in the frame of the normal
+        const float z = sqrt1(1.0f - r2), sr = sqrt1(r2);
+        return lincomb3(T, cp * sr, B, sp * sr, h.normal, z);
     }
+    float rough = max1(h.roughness, 0.04f);
+    v3 N = ggx_normal_from(sp, cp, r2, h.normal, T, B, rough);
+    if (r < diffuse_p + specular_p) return reflect3(neg3(V), N);
+    float eta = front ? rcp1(h.ior) : h.ior;
+    if (!front) N = neg3(N);
+    float cos_t = dot3(N, V);
+    float sin_t = sqrt1(1.0f - cos_t * cos_t);
+    bool cannot_refract = eta * sin_t > 1.0f;
+    float F = reflectance(__builtin_fabsf(cos_t), eta);
+    if (cannot_refract || (rng_f(rng) < F)) return reflect3(neg3(V), N);   // short-circuit: draw only if needed
+    return refract3(neg3(V), N, eta);
 }
 // evalBSDF, pt.wgsl:548-614: (f*cos, pdf)
 PT_DEV v4 eval_bsdf(const HitInfo &h, v3 normal, v3 V, v3 L, bool front) {
