@@ -42,9 +42,6 @@ namespace {
 #ifndef PT_OWN_REFILL_AT
 #define PT_OWN_REFILL_AT PT_REFILL_AT
 #endif
-#ifndef PT_XCD_BLOCKS
-#define PT_XCD_BLOCKS 1          /* 0: the from-memory kernels deal groups out wave by wave like the others (A/B) */
-#endif
 
 typedef const __attribute__((address_space(1))) uint32_t *glb_u32p;
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
@@ -181,27 +178,7 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
     const uint32_t lane = threadIdx.x & 63u;
     gw = uniform(gw);
     const uint32_t ngroups = (count + 63u) >> 6;
-    // Which 64-slot groups this wave traces. Scene in LDS: gw, gw + total_waves, ... — neighbouring groups on neighbouring waves.
-    // Scene in memory (XCD_BLOCKS): the queue in blocks of 2^lb groups dealt out to the eight XCDs in turn, the waves of an XCD (the
-    // workgroups with equal blockIdx.x % 8: MI355X_MICROARCH.md, workgroup dispatch) interleaved over that XCD's blocks. Neighbouring
-    // slots hold paths of neighbouring pixels; dealt out group by group every XCD's L2 (4 MiB, private) would see rays from all over
-    // the block being traced and hold the same 1 / 8 of it as the seven others, block-wise each holds its own part. A wrong guess
-    // about the placement costs speed, nothing else: every group is traced exactly once whatever runs where.
-    constexpr bool XCD_BLOCKS = REFILL == PT_REFILL_GLOBAL && PT_REFILL_GLOBAL != PT_OWN_REFILL_AT && PT_XCD_BLOCKS;
-    const bool by_xcd = XCD_BLOCKS && (gridDim.x & 7u) == 0u;
-    uint32_t lb = 0u, xcd = 0u, wx = gw, wpx = total_waves;       // block size (log2 groups), this wave's XCD label, its rank among / the number of that XCD's waves
-    uint32_t end;
-    if (by_xcd) {
-        xcd = blockIdx.x & 7u; wpx = total_waves >> 3; wx = (threadIdx.x >> 6) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-        lb = 10u;                                                  // 1024 groups = 65 536 slots: more than an XCD's waves hold at once
-        while (lb > 6u && (ngroups >> lb) < 128u) lb--;            // small queues: at least 16 blocks per XCD, for the balance
-        const uint32_t bsz = 1u << lb, nb = (ngroups + bsz - 1u) >> lb;
-        const uint32_t nbx = nb > xcd ? (nb - xcd + 7u) >> 3 : 0u;
-        const uint32_t nx = nbx * bsz - ((nbx != 0u && ((nb - 1u) & 7u) == xcd) ? nb * bsz - ngroups : 0u);      // groups of this XCD
-        end = wx < nx ? ((nx - wx + wpx - 1u) / wpx) * 64u : 0u;
-    } else {
-        end = gw < ngroups ? ((ngroups - gw + total_waves - 1u) / total_waves) * 64u : 0u;
-    }
+    const uint32_t end = gw < ngroups ? ((ngroups - gw + total_waves - 1u) / total_waves) * 64u : 0u;
     uint32_t next = 0u;
     bool active = false, slow = false;
     bool fin = false, fin_occ = false;      // the ray has finished; its winner is verified and its result written at the next refill
@@ -264,9 +241,7 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
             const uint64_t idle = ~act;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             const uint32_t vi = next + rank;
-            uint32_t grp = (vi >> 6) * wpx + wx;                  // the wave's (vi / 64)-th group: among all groups, or among its XCD's
-            if (by_xcd) grp = ((((grp >> lb) << 3) + xcd) << lb) + (grp & ((1u << lb) - 1u));
-            const uint32_t vslot = grp * 64u + (vi & 63u);
+            const uint32_t vslot = ((vi >> 6) * total_waves + gw) * 64u + (vi & 63u);
             if (!active && vi < end && vslot < count) {
                 slot = vslot;
                 const bool want = io.fetch(slot, o, d, tlim);
@@ -489,15 +464,15 @@ __global__ __launch_bounds__(GBLOCK) void k_own_global(const DevScene *__restric
     if constexpr (QUANT) {
         __shared__ uint4 qcache[2 * PT_QCACHE_NODES];
         const uint32_t nc = sc.q_cached < PT_QCACHE_NODES ? sc.q_cached : PT_QCACHE_NODES;
-        // (which waves have work is trace_wave_own's business: with the queue dealt out in blocks per XCD it is not "the first ones")
-        if (count == 0u) return;
+        if (blockIdx.x * 64u >= count) return;
         for (uint32_t i = threadIdx.x; i < 2u * nc; i += GBLOCK) qcache[i] = sc.qnodes[i];
         __syncthreads();
+        if (gw * 64u >= count) return;
         OwnQuantMem<false, false> m{(lds_u4p)qcache, (glb_u4p)sc.qnodes, nc, (lds_f4p)nullptr, (glb_f4p)sc.tripos,
                                     sc.q_origin[0], sc.q_origin[1], sc.q_origin[2], sc.q_scale[0], sc.q_scale[1], sc.q_scale[2]};
         trace_wave_own<MODE, CULL, 16, true, PT_REFILL_GLOBAL>(m, sc, io, count, gw, gridDim.x * (GBLOCK / 64), stk + threadIdx.x, GBLOCK, sp, gridDim.x * GBLOCK);
     } else {
-        if (count == 0u) return;
+        if (gw * 64u >= count) return;
         OwnGlobalMem m{(glb_f4p)sc.wnodes, (glb_f4p)sc.tripos};
         trace_wave_own<MODE, CULL, 16, true, PT_REFILL_GLOBAL>(m, sc, io, count, gw, gridDim.x * (GBLOCK / 64), stk + threadIdx.x, GBLOCK, sp, gridDim.x * GBLOCK);
     }
