@@ -278,6 +278,7 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
         if (REF) inv_old = rcp3(d);                                     // (the fast lanes keep what their box test needs in `pre`)
         if (run_tri) {
             bool ct = can_tri;
+            uint64_t ctm = bt;
 #pragma unroll 1
             for (int rep = 0; rep < LEAF_STEPS; rep++) {
                 UTIL(6, 1); UTIL(7, popc(ballot(ct)));
@@ -310,12 +311,16 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
                     }
                 }
                 if (rep + 1 < LEAF_STEPS) {
+                    // (the count comes from the lane masks of the comparisons themselves: a ballot of the combined verdict would first
+                    // be rebuilt as a 0 / 1 integer per lane — two vector instructions a step)
                     ct = ct & (lp != top) & !occluded;
-                    if (popc(ballot(ct)) * LEAF_KEEP < popc(bt)) break;
+                    ctm = ctm & ballot(lp != top) & ~ballot(occluded);
+                    if (popc(ctm) * LEAF_KEEP < popc(bt)) break;
                 }
             }
         } else {
             bool cn = can_node;
+            uint64_t cnm = bn;
             constexpr int NODE_UNROLL = SPILL ? PT_SPILL_NODE_UNROLL : NODE_STEPS;
 #pragma unroll NODE_UNROLL
             for (int rep = 0; rep < NODE_STEPS; rep++) {
@@ -338,7 +343,10 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
                         m.test(cur, pre, tl, tr, hl, hr, lref, rref);
                     }
                     if (CULL) { hl = hl & !(tl > limit); hr = hr & !(tr > limit); }
-                    const bool ll = (lref & LEAF_BIT) != 0u, rl = (rref & LEAF_BIT) != 0u;
+                    // (a reference is a leaf iff its top bit is set — of the 32 bits, or of the 16 the compact references use: written as a
+                    // comparison, which is one v_cmp into a lane mask; as a bit test the compiler builds the verdicts as 0 / 1 integers
+                    // in vector registers, five instructions a child)
+                    const bool ll = lref >= LEAF_BIT, rl = rref >= LEAF_BIT;
                     if (hl & ll) { *lp = (E)lref; lp -= stride; }
                     if (hr & rl) { *lp = (E)rref; lp -= stride; }
                     const bool il = hl & !ll, ir = hr & !rl;
@@ -359,7 +367,10 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
                 }
                 if (rep + 1 < NODE_STEPS) {
                     cn = cn & (cur != PT_REF_NONE) & ((int)room(lp, sp, stride) | (int)(SPILL && (sp != bot) & room(lp, bot, stride)));
-                    if (popc(ballot(cn)) * NODE_KEEP < popc(bn)) break;
+                    uint64_t rm = ballot(room(lp, sp, stride));
+                    if (SPILL) rm |= ballot(sp != bot) & ballot(room(lp, bot, stride));
+                    cnm = cnm & ballot(cur != PT_REF_NONE) & rm;
+                    if (popc(cnm) * NODE_KEEP < popc(bn)) break;
                 }
             }
         }
