@@ -73,6 +73,7 @@ struct OwnLdsMem {
     lds_f4p wn, tl; glb_f4p tg;
     struct Pre { v3 inv, n; };
     PT_DEV Pre prep(v3 o, v3 inv) const { return Pre{inv, mk3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z))}; }
+    PT_DEV v3 inv_of(const Pre &p, v3) const { return p.inv; }          // 1 / d as the ray keeps it
     PT_DEV void test(uint32_t i, const Pre &p, float &tl_, float &tr_, bool &hl, bool &hr, uint32_t &lref, uint32_t &rref) const {
         lds_f4p q = wn + 4u * i;
         const float4 a = as_f4(q[0]), b = as_f4(q[1]), c = as_f4(q[2]), r = as_f4(q[3]);
@@ -89,6 +90,7 @@ struct OwnGlobalMem {
     glb_f4p wn, tg;
     struct Pre { v3 inv, n; };
     PT_DEV Pre prep(v3 o, v3 inv) const { return Pre{inv, mk3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z))}; }
+    PT_DEV v3 inv_of(const Pre &p, v3) const { return p.inv; }
     PT_DEV void test(uint32_t i, const Pre &p, float &tl_, float &tr_, bool &hl, bool &hr, uint32_t &lref, uint32_t &rref) const {
         float4 a, b, c, r; load_node(wn + 4u * (size_t)i, a, b, c, r);
         hl = slab_fma(a.x, a.y, a.z, a.w, b.x, b.y, p.inv, p.n, tl_);
@@ -112,6 +114,7 @@ struct OwnQuantMem {
         const v3 n = mk3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
         return Pre{mk3(sx * inv.x, sy * inv.y, sz * inv.z), mk3(fma1(ox, inv.x, n.x), fma1(oy, inv.y, n.y), fma1(oz, inv.z, n.z))};
     }
+    PT_DEV v3 inv_of(const Pre &, v3 d) const { return rcp3(d); }        // (the quantised test keeps scale / d, not 1 / d)
     PT_DEV void test(uint32_t i, const Pre &p, float &tl_, float &tr_, bool &hl, bool &hr, uint32_t &lref, uint32_t &rref) const {
         u4v l, r;
         if (ALL_IN_LDS || i < n_cached) { l = qc[2u * i]; r = qc[2u * i + 1u]; }
@@ -197,16 +200,22 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
 
     // (re)start this lane's ray: the root test, then the root of the tree its kind of ray walks
     auto start = [&](bool slow_ray, v3 inv) -> bool {
+        // (the boxes are uniform — scalar loads — and almost no wave holds a slow ray: its box is tested in a branch the whole wave
+        // takes or skips; written as two operands selected per lane the compiler loads every bound from a per-lane address, six vector
+        // loads and their latency in the wave's refill)
         float tm;
-        const bool hit = slow_ray ? slab(sc.ref_root_min[0], sc.ref_root_min[1], sc.ref_root_min[2],
-                                         sc.ref_root_max[0], sc.ref_root_max[1], sc.ref_root_max[2], o, inv, tm)
-                                  : slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], o, inv, tm);
+        bool hit = slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], o, inv, tm);
+        uint32_t r = R16 ? sc.root_ref16 : sc.root_ref;
+        if (ballot(slow_ray) != 0ull) {
+            const bool h2 = slab(sc.ref_root_min[0], sc.ref_root_min[1], sc.ref_root_min[2], sc.ref_root_max[0], sc.ref_root_max[1], sc.ref_root_max[2], o, inv, tm);
+            const uint32_t r2 = R16 ? sc.ref_root_ref16 : sc.ref_root_ref;
+            hit = slow_ray ? h2 : hit; r = slow_ray ? r2 : r;
+        }
         best.t = __builtin_inff(); best.tri = PT_REF_NONE;
         sp = bot; lp = top; spn = 0u; cur = PT_REF_NONE;
         limit = (ANY && CULL) ? cull_limit(tlim) : __builtin_inff();      // NaN for a directional light: never culls
         if (!hit) return false;
-        const uint32_t r = R16 ? (slow_ray ? sc.ref_root_ref16 : sc.root_ref16) : (slow_ray ? sc.ref_root_ref : sc.root_ref);
-        if (r & LEAF_BIT) { *lp = (E)r; lp -= stride; }                   // a one-leaf tree: file the root
+        if (r >= LEAF_BIT) { *lp = (E)r; lp -= stride; }                  // a one-leaf tree: file the root
         else cur = r;
         return true;
     };
@@ -224,7 +233,7 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
                     glb_f4p lb = (glb_f4p)sc.tri_leafbox + 2u * (size_t)best.tri;
                     const float4 lo = as_f4(lb[0]), hi = as_f4(lb[1]);
                     float tm;
-                    redo = !slab(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, o, rcp3(d), tm);
+                    redo = !slab(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, o, m.inv_of(pre, d), tm);
                 }
                 fin = false;
                 if (redo) {                                             // never its own: the uploaded tree decides (at most once per ray)
