@@ -115,6 +115,9 @@ struct ExtendIO {
         return true;
     }
     PT_DEV void finish(uint32_t slot, const Hit &h, bool) const { st_stream(&hits[slot], pack_hit(h)); }
+    // (traverse_own.hip: `aux` is a word a lane keeps from fetch to finish — the any-hit kernel's path id; nothing here)
+    PT_DEV bool fetch(uint32_t slot, v3 &o, v3 &d, float &tlim, uint32_t &) const { return fetch(slot, o, d, tlim); }
+    PT_DEV void finish(uint32_t slot, const Hit &h, bool occ, uint32_t) const { finish(slot, h, occ); }
 };
 // The records of a bounce are one allocation (pt_device.h DevShadow): the kernel keeps its base and `cap` instead of three
 // pointers, and the radiance buffer instead of the whole path state — the node-cache variant needs at most 80 scalar
@@ -133,9 +136,21 @@ struct ShadowIO {
         tlim = so.w < 0.0f ? __builtin_nanf("") : so.w - PT_EPS * 2.0f;
         return so.w != -2.0f;
     }
-    PT_DEV void finish(uint32_t i, const Hit &, bool occluded) const {
+    PT_DEV void finish(uint32_t i, const Hit &h, bool occluded) const {
+        if (!occluded) finish(i, h, occluded, __float_as_uint(rec[(size_t)cap + i].w));
+    }
+    // the path id travels in the lane from fetch (it is SD.w of the record fetch reads anyway) to finish: the radiance and the
+    // contribution are then loaded together instead of one after a reload of the record
+    PT_DEV bool fetch(uint32_t &slot, v3 &o, v3 &d, float &tlim, uint32_t &path) const {
+        uint32_t i = sq ? sq[slot] : slot;
+        slot = i;
+        float4 so = ld_stream(&rec[i]), sd = ld_stream(&rec[(size_t)cap + i]);
+        o = xyz(so); d = xyz(sd); path = __float_as_uint(sd.w);
+        tlim = so.w < 0.0f ? __builtin_nanf("") : so.w - PT_EPS * 2.0f;
+        return so.w != -2.0f;
+    }
+    PT_DEV void finish(uint32_t i, const Hit &, bool occluded, uint32_t p) const {
         if (!occluded) {
-            const uint32_t p = __float_as_uint(rec[(size_t)cap + i].w);
             DevPaths P; P.O = nullptr; P.D = nullptr; P.C = nullptr; P.L = L; P.l_stride = l_stride;
             const rgb_sc l = P.ldL(p), c = reinterpret_cast<const rgb_sc *>(rec + 2 * (size_t)cap)[i];
             P.stL(p, l.x + c.x, l.y + c.y, l.z + c.z);   // pt.wgsl:675
@@ -150,6 +165,8 @@ struct OccludedIO {
         return s.fetch(slot, o, d, tlim);
     }
     PT_DEV void finish(uint32_t i, const Hit &, bool occluded) const { occluded_out[i] = occluded ? 1 : 0; }
+    PT_DEV bool fetch(uint32_t &slot, v3 &o, v3 &d, float &tlim, uint32_t &) const { return fetch(slot, o, d, tlim); }
+    PT_DEV void finish(uint32_t i, const Hit &h, bool occluded, uint32_t) const { finish(i, h, occluded); }
 };
 
 }  // namespace

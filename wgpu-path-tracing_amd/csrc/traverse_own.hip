@@ -185,7 +185,7 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
     uint32_t next = 0u;
     bool active = false, slow = false;
     bool fin = false, fin_occ = false;      // the ray has finished; its winner is verified and its result written at the next refill
-    uint32_t slot = 0, cur = PT_REF_NONE;
+    uint32_t slot = 0, cur = PT_REF_NONE, aux = 0;      // aux: what the ray's IO keeps from fetch to finish (ShadowIO: the path id)
     const lds_ep bot = (lds_ep)stk, top = bot + ((STACK ? STACK : nstack) - 1) * stride;
     lds_ep sp = bot, lp = top;
     uint32_t spn = 0;
@@ -239,9 +239,9 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
                 if (redo) {                                             // never its own: the uploaded tree decides (at most once per ray)
                     slow = true; n_redo++;
                     if (start(true, rcp3(d))) active = true;
-                    else io.finish(slot, best, false);
+                    else io.finish(slot, best, false, aux);
                 } else {
-                    io.finish(slot, best, fin_occ);
+                    io.finish(slot, best, fin_occ, aux);
                 }
             }
             act = ballot(active);
@@ -253,7 +253,7 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
             const uint32_t vslot = ((vi >> 6) * total_waves + gw) * 64u + (vi & 63u);
             if (!active && vi < end && vslot < count) {
                 slot = vslot;
-                const bool want = io.fetch(slot, o, d, tlim);
+                const bool want = io.fetch(slot, o, d, tlim, aux);
                 const v3 inv = rcp3(d);
                 pre = m.prep(o, inv);
                 // the padding covers the fused test's rounding only for rays without huge or vanishing slopes, from origins near the
@@ -266,7 +266,7 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
                                     (__builtin_fabsf(o.z) <= sc.safe_origin);
                 slow = !(regular & bounded & near_o);
                 if (want && sc.root_ref != PT_REF_NONE && start(slow, inv)) active = true;
-                else { best.t = __builtin_inff(); best.tri = PT_REF_NONE; io.finish(slot, best, false); }
+                else { best.t = __builtin_inff(); best.tri = PT_REF_NONE; io.finish(slot, best, false, aux); }
             }
             next += (uint32_t)__popcll(idle);
             UTIL(2, 1); UTIL(3, popc(ballot(active)) - popc(act));
