@@ -41,13 +41,14 @@ def force(kind, code):
 
 
 def more_rays(sc, n, seed):
-    """_test_rays + origins far outside the scene and directions with a tiny component: the rays that take the slow way"""
+    """_test_rays + origins far outside the scene and directions with a tiny or a huge component: the rays that take the slow way"""
     o, d = _test_rays(sc, n, seed)
     rng = np.random.default_rng(seed + 1)
     k = n // 10
     d[-k:, rng.integers(0, 3)] = np.float32(1e-20)
     far = slice(n - 2 * k, n - k)
     o[far] = (o[far] - d[far] * np.float32(500.0)).astype(np.float32)
+    d[n - 3 * k:n - 2 * k, rng.integers(0, 3)] = np.float32(3e25)      # a component beyond 2^60: the reference's business too
     return o, d
 
 

@@ -132,8 +132,8 @@ static void trace_one(const own_sim_scene *s, int own, int quant, int cull, int 
     const int any = dist != 0.0f;
     const float tlim = !any ? 0.0f : (dist < 0.0f ? NAN : dist - EPS * 2.0f);
     v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const float big = 0x1p60f;
-    int regular = (fabsf(inv.x) <= big) & (fabsf(inv.y) <= big) & (fabsf(inv.z) <= big) & (inv.x != 0.0f) & (inv.y != 0.0f) & (inv.z != 0.0f);
+    const float lo = 0x1p-60f, hi = 0x1p60f;     /* traverse_own.hip: direction components within [2^-60, 2^60] */
+    int regular = (fabsf(d.x) >= lo) & (fabsf(d.x) <= hi) & (fabsf(d.y) >= lo) & (fabsf(d.y) <= hi) & (fabsf(d.z) >= lo) & (fabsf(d.z) <= hi);
     int bounded = (fabsf(d.x) + fabsf(d.y) + fabsf(d.z)) <= s->tri_safe_dsum;
     int near_o = (fabsf(o.x) <= s->safe_origin) & (fabsf(o.y) <= s->safe_origin) & (fabsf(o.z) <= s->safe_origin);
     if (!own) {                 /* the image over the reference's leaves (traverse.hip): only irregular rays walk the uploaded tree */

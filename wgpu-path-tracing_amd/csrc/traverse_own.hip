@@ -18,8 +18,8 @@
 //      is a triangle the reference tests too, and being the minimum over a superset it is the reference's minimum;
 //   3. if it fails — the reference would never have tested that triangle: a ray grazing the leaf box within rounding — the ray is
 //      traced again over the tree exactly as uploaded (the `slow` path below), which is the reference's computation itself. The same
-//      path takes every ray the argument of 1. does not cover: a zero / subnormal / non-finite direction component or one below
-//      2^-60, an origin farther than DevScene::safe_origin from the coordinate origin, an unbounded triangle-test determinant.
+//      path takes every ray the argument of 1. does not cover: a zero / subnormal / non-finite direction component or one outside
+//      [2^-60, 2^60], an origin farther than DevScene::safe_origin from the coordinate origin, an unbounded triangle-test determinant.
 // So results equal traverse.hip's bit for bit unless a ray meets a triangle in Moller-Trumbore's arithmetic while missing that
 // triangle's padded bounding box — the padding is 2^-16 of the scene's largest coordinate, 16 x the rounding of the fused test for
 // origins inside the scene; tests/test_gpu_own_leaves.py counts such rays (none in 10^8 and more).
@@ -254,17 +254,20 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
             if (!active && vi < end && vslot < count) {
                 slot = vslot;
                 const bool want = io.fetch(slot, o, d, tlim, aux);
-                const v3 inv = rcp3(d);
-                pre = m.prep(o, inv);
                 // the padding covers the fused test's rounding only for rays without huge or vanishing slopes, from origins near the
-                // scene; every other ray is the reference's own business (NaN compares false: slow)
-                const float big = 0x1p60f;
-                const bool regular = (__builtin_fabsf(inv.x) <= big) & (__builtin_fabsf(inv.y) <= big) & (__builtin_fabsf(inv.z) <= big) &
-                                     (inv.x != 0.0f) & (inv.y != 0.0f) & (inv.z != 0.0f);
-                const bool bounded = (__builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z)) <= sc.tri_safe_dsum;
+                // scene; every other ray is the reference's own business (NaN compares false: slow). A regular ray's direction
+                // components lie within [2^-60, 2^60], where the short reciprocal is the correctly rounded one (pt_math.h) and needs no
+                // range test of its own; the others get the IEEE quotient, in a branch a wave almost never takes.
+                const float lo = 0x1p-60f, hi = 0x1p60f;
+                const float ax = __builtin_fabsf(d.x), ay = __builtin_fabsf(d.y), az = __builtin_fabsf(d.z);
+                const bool regular = (ax >= lo) & (ax <= hi) & (ay >= lo) & (ay <= hi) & (az >= lo) & (az <= hi);
+                const bool bounded = (ax + ay + az) <= sc.tri_safe_dsum;
                 const bool near_o = (__builtin_fabsf(o.x) <= sc.safe_origin) & (__builtin_fabsf(o.y) <= sc.safe_origin) &
                                     (__builtin_fabsf(o.z) <= sc.safe_origin);
                 slow = !(regular & bounded & near_o);
+                v3 inv = PT_IEEE_EXPANSIONS ? rcp3(d) : mk3(rcp_short(d.x), rcp_short(d.y), rcp_short(d.z));
+                if (!PT_IEEE_EXPANSIONS && slow) inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                pre = m.prep(o, inv);
                 if (want && sc.root_ref != PT_REF_NONE && start(slow, inv)) active = true;
                 else { best.t = __builtin_inff(); best.tri = PT_REF_NONE; io.finish(slot, best, false, aux); }
             }
