@@ -40,7 +40,7 @@ namespace {
 
 // refill when at most this many of the 64 lanes still hold a ray (scene in LDS; traverse_common.h has the value of the other kernels)
 #ifndef PT_OWN_REFILL_AT
-#define PT_OWN_REFILL_AT PT_REFILL_AT
+#define PT_OWN_REFILL_AT 44   /* (36 until session 24: a refill is 35 vector instructions and seven loads cheaper now; config 2 +1 %, config 1 +-0) */
 #endif
 
 typedef const __attribute__((address_space(1))) uint32_t *glb_u32p;
