@@ -3,7 +3,10 @@
 the reference's (leaves = 1, the mode the parity tests pin to the oracle): the frames must be equal bit for bit and the counters equal —
 every ray of the render found the same (t, triangle) / verdict, or a pixel would differ. Prints the rays counted (path segments + traced
 shadow rays) and how many were traced again after a failed verification.
-usage (GPU box): python tools/leaf_modes_equal_gpu.py [repeat=1]     (repeat: more accumulation passes with later frame indices)"""
+usage (GPU box): python tools/leaf_modes_equal_gpu.py [repeat=1] [leaves|cull]    (repeat: more accumulation passes with later frame indices)
+With `cull`: the distance cull (ptmi_options.cull = 1, the default: boxes beyond the closest hit so far are skipped) against
+cull = 0 over the reference's leaves — the two may differ where Moller-Trumbore reports a hit outside its triangle's box (a grazing ray);
+the run counts how often."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "wgpu-path-tracing_amd"))
@@ -11,6 +14,7 @@ import numpy as np
 from ptmi import layout, native, scenes
 
 repeat = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+what = sys.argv[2] if len(sys.argv) > 2 else "leaves"
 CASES = [("configs[1]", "cornell", 1920, 1080, 64, 0.001, 5.0), ("configs[2]", "cornell_spheres", 1920, 1080, 512, 0.001, 5.0),
          ("configs[3]", "grid_1m", 1920, 1080, 64, 0.001, 5.0), ("configs[4]", "cornell", 3840, 2160, 256, 0.05, 2.8)]
 ctx = native.Context(0)
@@ -19,10 +23,11 @@ for tag, name, W, H, spp, ap, focus in CASES:
     sc = scenes.grid_1m() if name == "grid_1m" else scenes.make(name)
     for rep in range(repeat):
         imgs, stats = [], []
-        for leaves in (1, 2):
-            ctx.set_options(leaves=leaves, leaf_tris=0, keep_reference_tree=0, traversal=native.TRAVERSAL_AUTO, cull=1)
+        for mode in (1, 2):
+            leaves, cull = (mode, 1) if what == "leaves" else (1, 2 - mode)
+            ctx.set_options(leaves=leaves, leaf_tris=0, keep_reference_tree=0, traversal=native.TRAVERSAL_AUTO, cull=cull)
             ctx.upload_scene(sc); ctx.resize(W, H)
-            ctx.set_options(max_bounces=8, do_mis=1, tile_y0=0, tile_y1=0, frames_per_batch=0)
+            ctx.set_options(max_bounces=8, do_mis=1, tile_y0=0, tile_y1=0, frames_per_batch=0, cull=cull)
             ctx.reset_stats()
             cam = layout.make_camera(W, H, aperture=ap, focus_distance=focus, frame_index=rep * spp)
             t0 = time.time()
