@@ -175,8 +175,7 @@ PT_DEV void trace_wave_own(const Mem &m, const DevScene &sc, const IO &io, uint3
 #ifndef PT_OWN_NODE_KEEP_SHADOW
 #define PT_OWN_NODE_KEEP_SHADOW 4
 #endif
-    static_assert(PT_OWN_REFILL_AT != PT_REFILL_GLOBAL, "the kernels that walk memory are told from the LDS ones by their refill threshold");
-    constexpr bool FROM_MEMORY = REFILL == PT_REFILL_GLOBAL;
+    constexpr bool FROM_MEMORY = REFILL == PT_REFILL_GLOBAL && PT_REFILL_GLOBAL != PT_OWN_REFILL_AT;
     constexpr int NODE_KEEP = FROM_MEMORY ? (ANY ? 2 : 3) : (ANY ? PT_OWN_NODE_KEEP_SHADOW : PT_OWN_NODE_KEEP_EXTEND);
     constexpr int NODE_STEPS = PT_OWN_NODE_STEPS, LEAF_STEPS = PT_OWN_LEAF_STEPS, LEAF_KEEP = PT_OWN_LEAF_KEEP;
     const uint32_t lane = threadIdx.x & 63u;
